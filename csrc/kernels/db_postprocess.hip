@@ -1,0 +1,220 @@
+// DB (differentiable binarisation) post-processing on the GPU.
+//
+// Replaces the OpenCV findContours + pyclipper + shapely chain of the
+// reference's dependency stack with four small kernels that never move the
+// full-resolution mask to the host:
+//   1. ccl_init     parent[p] = p for foreground pixels, -1 for background
+//   2. ccl_merge    union-find over left / up / up-left / up-right neighbours
+//                   (8-connectivity), lock-free with atomicMin on roots
+//   3. ccl_assign   path-compress and give every root a compact component id
+//      ccl_stats    reduce per-component bbox / probability sum / pixel count.
+//                   Lanes of a wave that hit the same component are combined
+//                   in-register first (text blobs are wide, so a wave64 almost
+//                   always sits inside one component) -> one atomic set per
+//                   wave instead of 64 contended ones.
+//   4. box_finalize score filter, closed-form rectangle "unclip"
+//                   (d = area * ratio / perimeter), rescale to page pixels.
+// Output is a small [B, max_boxes, 6] float table + per-page counts.
+#include "common.h"
+
+#define MAXC_DEFAULT 4096
+
+// Page-local indices are used inside parent[] (index within the page).
+__global__ void ccl_init_local_kernel(const uint8_t* __restrict__ mask, int* __restrict__ parent, int hw, int B) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  int b = blockIdx.y;
+  if (p >= hw) return;
+  long long g = (long long)b * hw + p;
+  parent[g] = mask[g] ? p : -1;
+}
+
+__device__ __forceinline__ int uf_find(int* parent, int x) {
+  int r = x;
+  while (true) {
+    int pr = parent[r];
+    if (pr == r) break;
+    r = pr;
+  }
+  return r;
+}
+
+__device__ __forceinline__ void uf_union(int* parent, int a, int b) {
+  while (true) {
+    a = uf_find(parent, a);
+    b = uf_find(parent, b);
+    if (a == b) return;
+    if (a < b) { int t = a; a = b; b = t; }   // a > b: attach a under b
+    int old = atomicMin(&parent[a], b);
+    if (old == a) return;
+    a = old;  // someone else changed it; retry with the new link
+  }
+}
+
+__global__ void ccl_merge_kernel(const uint8_t* __restrict__ mask, int* __restrict__ parent_all, int H, int W) {
+  int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  int b = blockIdx.z;
+  if (x >= W || y >= H) return;
+  const long long base = (long long)b * H * W;
+  const uint8_t* m = mask + base;
+  int* parent = parent_all + base;
+  int p = y * W + x;
+  if (!m[p]) return;
+  if (x > 0 && m[p - 1]) uf_union(parent, p, p - 1);
+  if (y > 0) {
+    if (m[p - W]) uf_union(parent, p, p - W);
+    else {
+      // only needed when the pixel straight above is background
+      if (x > 0 && m[p - W - 1]) uf_union(parent, p, p - W - 1);
+      if (x + 1 < W && m[p - W + 1]) uf_union(parent, p, p - W + 1);
+    }
+  }
+}
+
+// Path-compress every foreground pixel to its root and give each root a compact id.
+__global__ void ccl_assign_kernel(int* __restrict__ parent_all, int* __restrict__ comp_id_all,
+                                  int* __restrict__ ncomp, int H, int W, int maxc) {
+  int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  int b = blockIdx.z;
+  if (x >= W || y >= H) return;
+  const long long base = (long long)b * H * W;
+  int* parent = parent_all + base;
+  int p = y * W + x;
+  if (parent[p] < 0) return;
+  int root = uf_find(parent, p);
+  if (root == p) {
+    int id = atomicAdd(&ncomp[b], 1);
+    comp_id_all[base + p] = id < maxc ? id : maxc;
+  } else {
+    parent[p] = root;  // benign race: every value ever stored is an ancestor of p
+  }
+}
+
+// stats layout per component: [xmin, ymin, xmax, ymax, count, sum(prob) as float bits]
+__global__ void ccl_stats_kernel(const bf16_t* __restrict__ prob, const int* __restrict__ parent_all,
+                                 const int* __restrict__ comp_id_all, int* __restrict__ stats, int H, int W,
+                                 int maxc) {
+  int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  int b = blockIdx.z;
+  const long long base = (long long)b * H * W;
+  const int* parent = parent_all + base;
+  bool inb = (x < W && y < H);
+  int p = y * W + x;
+  int cid = -1;
+  float pv = 0.f;
+  if (inb) {
+    int root = parent[p];
+    if (root >= 0) {
+      // after ccl_assign every parent is either the root or one hop from it
+      int r2 = parent[root];
+      if (r2 != root) { root = r2; int r3 = parent[root]; while (r3 != root) { root = r3; r3 = parent[root]; } }
+      cid = comp_id_all[base + root];
+      pv = (float)prob[base + p];
+    }
+  }
+  // wave-level combine of lanes with the same component
+  bool active = (cid >= 0 && cid < maxc);
+  int xmin = x, xmax = x, ymin = y, ymax = y, cnt = 1;
+  float ps = pv;
+  unsigned long long todo = __ballot(active);
+  while (todo) {
+    int leader = __ffsll((long long)todo) - 1;
+    int lc = __shfl(cid, leader, 64);
+    bool same = active && (cid == lc);
+    unsigned long long grp = __ballot(same);
+    // reduce over the group (all lanes participate in shuffles; non-members contribute identities)
+    int vxmin = same ? xmin : 0x7fffffff, vxmax = same ? xmax : -1;
+    int vymin = same ? ymin : 0x7fffffff, vymax = same ? ymax : -1;
+    int vcnt = same ? cnt : 0;
+    float vps = same ? ps : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      vxmin = min(vxmin, __shfl_xor(vxmin, o, 64));
+      vxmax = max(vxmax, __shfl_xor(vxmax, o, 64));
+      vymin = min(vymin, __shfl_xor(vymin, o, 64));
+      vymax = max(vymax, __shfl_xor(vymax, o, 64));
+      vcnt += __shfl_xor(vcnt, o, 64);
+      vps += __shfl_xor(vps, o, 64);
+    }
+    if ((int)(threadIdx.x & 63) == leader) {
+      int* s = stats + ((long long)b * maxc + lc) * 6;
+      atomicMin(&s[0], vxmin);
+      atomicMin(&s[1], vymin);
+      atomicMax(&s[2], vxmax);
+      atomicMax(&s[3], vymax);
+      atomicAdd(&s[4], vcnt);
+      atomicAdd(reinterpret_cast<float*>(&s[5]), vps);
+    }
+    todo &= ~grp;
+  }
+}
+
+__global__ void stats_init_kernel(int* __restrict__ stats, int* __restrict__ ncomp, int* __restrict__ nbox, int n,
+                                  int B) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) { ncomp[i] = 0; nbox[i] = 0; }
+  if (i >= n) return;
+  int* s = stats + (long long)i * 6;
+  s[0] = 0x7fffffff; s[1] = 0x7fffffff; s[2] = -1; s[3] = -1; s[4] = 0; s[5] = 0;
+}
+
+// page_scale: [B, 2] float (sx, sy): multiply det-map coords to get page pixel coords.
+// valid: [B, 2] int (valid_w, valid_h) of the det map (content area, rest is bucket padding)
+// boxes: [B, max_boxes, 6] float: x0, y0, x1, y1 (page pixels), score, pixel count
+__global__ void box_finalize_kernel(const int* __restrict__ stats, const int* __restrict__ ncomp,
+                                    const float* __restrict__ page_scale, const int* __restrict__ valid,
+                                    float* __restrict__ boxes, int* __restrict__ nbox, int maxc, int max_boxes,
+                                    float box_thresh, float unclip_ratio, int min_size, int H, int W) {
+  int cidx = blockIdx.x * blockDim.x + threadIdx.x;
+  int b = blockIdx.y;
+  int nc = min(ncomp[b], maxc);
+  if (cidx >= nc) return;
+  const int* s = stats + ((long long)b * maxc + cidx) * 6;
+  int cnt = s[4];
+  if (cnt <= 0) return;
+  float score = __builtin_bit_cast(float, s[5]) / (float)cnt;
+  float x0 = (float)s[0], y0 = (float)s[1], x1 = (float)(s[2] + 1), y1 = (float)(s[3] + 1);
+  float w = x1 - x0, h = y1 - y0;
+  if (fminf(w, h) < (float)min_size) return;
+  if (score < box_thresh) return;
+  float d = (w * h) * unclip_ratio / (2.f * (w + h));
+  int vw = valid ? valid[b * 2] : W, vh = valid ? valid[b * 2 + 1] : H;
+  x0 = fmaxf(x0 - d, 0.f); y0 = fmaxf(y0 - d, 0.f);
+  x1 = fminf(x1 + d, (float)vw); y1 = fminf(y1 + d, (float)vh);
+  if (x1 - x0 < (float)(min_size + 2) || y1 - y0 < (float)(min_size + 2)) return;
+  float sx = page_scale ? page_scale[b * 2] : 1.f, sy = page_scale ? page_scale[b * 2 + 1] : 1.f;
+  int slot = atomicAdd(&nbox[b], 1);
+  if (slot >= max_boxes) return;
+  float* o = boxes + ((long long)b * max_boxes + slot) * 6;
+  o[0] = x0 * sx; o[1] = y0 * sy; o[2] = x1 * sx; o[3] = y1 * sy; o[4] = score; o[5] = (float)cnt;
+}
+
+// mask: [B,H,W] u8, prob: [B,H,W] bf16.  Workspaces: parent, comp_id: [B,H,W] int32;
+// stats: [B,maxc,6] int32; ncomp, nbox: [B] int32.
+extern "C" int dlamd_db_postprocess(const void* mask, const void* prob, void* parent, void* comp_id, void* stats,
+                                    void* ncomp, void* nbox, const float* page_scale, const int* valid, float* boxes,
+                                    int B, int H, int W, int maxc, int max_boxes, float box_thresh,
+                                    float unclip_ratio, int min_size, hipStream_t stream) {
+  if (B <= 0) return 0;
+  if ((long long)H * W > 0x7fffffffLL || B > 65535) return -1;
+  const int hw = H * W;
+  {
+    int n = B * maxc;
+    int nb = (max(n, B) + 255) / 256;
+    hipLaunchKernelGGL(stats_init_kernel, dim3(nb), dim3(256), 0, stream, (int*)stats, (int*)ncomp, (int*)nbox, n, B);
+  }
+  hipLaunchKernelGGL(ccl_init_local_kernel, dim3((hw + 255) / 256, B), dim3(256), 0, stream, (const uint8_t*)mask,
+                     (int*)parent, hw, B);
+  dim3 grid((W + 63) / 64, (H + 3) / 4, B);
+  hipLaunchKernelGGL(ccl_merge_kernel, grid, dim3(256), 0, stream, (const uint8_t*)mask, (int*)parent, H, W);
+  hipLaunchKernelGGL(ccl_assign_kernel, grid, dim3(256), 0, stream, (int*)parent, (int*)comp_id, (int*)ncomp, H, W,
+                     maxc);
+  hipLaunchKernelGGL(ccl_stats_kernel, grid, dim3(256), 0, stream, (const bf16_t*)prob, (const int*)parent,
+                     (const int*)comp_id, (int*)stats, H, W, maxc);
+  hipLaunchKernelGGL(box_finalize_kernel, dim3((maxc + 255) / 256, B), dim3(256), 0, stream, (const int*)stats,
+                     (const int*)ncomp, page_scale, valid, boxes, (int*)nbox, maxc, max_boxes, box_thresh,
+                     unclip_ratio, min_size, H, W);
+  return DLAMD_CHECK_LAUNCH();
+}

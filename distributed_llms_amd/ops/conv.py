@@ -1,0 +1,212 @@
+"""NHWC bf16 convolution / GEMM ops backed by the MFMA implicit-GEMM kernel.
+
+``conv2d_nhwc`` is the single entry point for every GEMM-shaped op of the OCR
+stack (DBNet convs, FPN fusion, transposed convs, CRNN convs, LSTM input
+projections, ViT / decoder linears).  On a CUDA(HIP) tensor it launches
+``dlamd_conv2d`` (csrc/kernels/conv_igemm.hip); on a CPU tensor it evaluates
+``conv2d_nhwc_reference`` (plain PyTorch fp32), which is also the numerics
+oracle for the GPU tests.
+
+Reference parity: the reference runs these layers through magic-pdf's CPU
+torch models (services/ocr_service/ocr_service.py:215-220,
+download_models_hf.py:36-44); nothing of that code exists in-tree, so the op
+contract here is new.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple, Union
+
+import torch
+import torch.nn.functional as F
+
+from . import _loader
+
+ACT = {"none": 0, "relu": 1, "hardswish": 2, "gelu": 3, "sigmoid": 4, "tanh": 5}
+OUT_PLAIN, OUT_PIXEL_SHUFFLE, OUT_REPLICATE, OUT_PROB = 0, 1, 2, 3
+RES_NONE, RES_SAME, RES_UP2 = 0, 1, 2
+
+IntPair = Union[int, Tuple[int, int]]
+
+
+def _pair(v: IntPair) -> Tuple[int, int]:
+    return (v, v) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+def _act_ref(v: torch.Tensor, act: str) -> torch.Tensor:
+    if act == "relu":
+        return F.relu(v)
+    if act == "hardswish":
+        return F.hardswish(v)
+    if act == "gelu":
+        return F.gelu(v)
+    if act == "sigmoid":
+        return torch.sigmoid(v)
+    if act == "tanh":
+        return torch.tanh(v)
+    return v
+
+
+def out_hw(H: int, W: int, kh: int, kw: int, sh: int, sw: int, ph: int, pw: int) -> Tuple[int, int]:
+    return (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+
+
+def conv2d_nhwc_reference(
+    x: torch.Tensor,
+    w: torch.Tensor,
+    bias: Optional[torch.Tensor] = None,
+    *,
+    stride: IntPair = 1,
+    padding: IntPair = 0,
+    act: str = "none",
+    res: Optional[torch.Tensor] = None,
+    res_mode: int = RES_NONE,
+    out_mode: int = OUT_PLAIN,
+    out_f: int = 1,
+    thr: float = 0.3,
+    out_dtype: torch.dtype = torch.bfloat16,
+):
+    """fp32 PyTorch oracle.  x: [B,H,W,Cin], w: [Cout,kh,kw,Cin]."""
+    sh, sw = _pair(stride)
+    ph, pw = _pair(padding)
+    xf = x.float().permute(0, 3, 1, 2)
+    wf = w.float().permute(0, 3, 1, 2)
+    y = F.conv2d(xf, wf, None if bias is None else bias.float(), stride=(sh, sw), padding=(ph, pw))
+    if res is not None and res_mode != RES_NONE:
+        r = res.float().permute(0, 3, 1, 2)
+        if res_mode == RES_UP2:
+            r = F.interpolate(r, scale_factor=2, mode="nearest")[:, :, : y.shape[2], : y.shape[3]]
+        y = y + r[:, : y.shape[1]]
+    y = _act_ref(y, act)
+    if out_mode == OUT_PROB:
+        # Cout == 4 -> 2x2 pixels: channel (dy*2+dx)
+        B, _, Ho, Wo = y.shape
+        p = y.view(B, 2, 2, Ho, Wo).permute(0, 3, 1, 4, 2).reshape(B, 2 * Ho, 2 * Wo)
+        return p.to(out_dtype), (p > thr).to(torch.uint8)
+    if out_mode == OUT_PIXEL_SHUFFLE:
+        B, C4, Ho, Wo = y.shape
+        Cp = C4 // 4
+        y = y.view(B, 2, 2, Cp, Ho, Wo).permute(0, 3, 4, 1, 5, 2).reshape(B, Cp, 2 * Ho, 2 * Wo)
+    elif out_mode == OUT_REPLICATE and out_f > 1:
+        y = F.interpolate(y, scale_factor=out_f, mode="nearest")
+    return y.permute(0, 2, 3, 1).contiguous().to(out_dtype)
+
+
+def conv2d_nhwc(
+    x: torch.Tensor,
+    w: torch.Tensor,
+    bias: Optional[torch.Tensor] = None,
+    *,
+    stride: IntPair = 1,
+    padding: IntPair = 0,
+    act: str = "none",
+    res: Optional[torch.Tensor] = None,
+    res_mode: int = RES_NONE,
+    out: Optional[torch.Tensor] = None,
+    out_coff: int = 0,
+    out_mode: int = OUT_PLAIN,
+    out_f: int = 1,
+    thr: float = 0.3,
+    out_dtype: torch.dtype = torch.bfloat16,
+    cfg: int = 0,
+):
+    """Fused conv (+bias +residual +activation) on NHWC bf16 tensors.
+
+    x   : [B, H, W, Cin]   (last-dim stride 1; the pixel stride may exceed Cin,
+                            i.e. x may be a channel slice of a wider buffer)
+    w   : [Cout, kh, kw, Cin] bf16
+    out : optional pre-allocated destination [B, Ho', Wo', Ctot]; the result is
+          written at channel offset ``out_coff`` (fused concat).
+    Returns the output tensor (or ``(prob, mask)`` for ``OUT_PROB``).
+    """
+    if not x.is_cuda:
+        y = conv2d_nhwc_reference(
+            x, w, bias, stride=stride, padding=padding, act=act, res=res, res_mode=res_mode,
+            out_mode=out_mode, out_f=out_f, thr=thr, out_dtype=out_dtype,
+        )
+        if out is not None and out_mode != OUT_PROB:
+            out[..., out_coff : out_coff + y.shape[-1]] = y
+            return out
+        return y
+
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16, "conv2d_nhwc expects bf16"
+    assert x.dim() == 4 and w.dim() == 4 and x.stride(3) == 1
+    B, H, W, Cin = x.shape
+    Cout, kh, kw, Cin_w = w.shape
+    assert Cin_w == Cin, f"weight Cin {Cin_w} != input Cin {Cin}"
+    assert w.is_contiguous()
+    x_cstride = x.stride(2)
+    assert x.stride(1) == W * x_cstride and x.stride(0) == H * W * x_cstride, "x must be pixel-contiguous"
+    sh, sw = _pair(stride)
+    ph, pw = _pair(padding)
+    Ho, Wo = out_hw(H, W, kh, kw, sh, sw, ph, pw)
+
+    mask = None
+    if out_mode == OUT_PROB:
+        assert Cout == 4
+        y = torch.empty((B, 2 * Ho, 2 * Wo), dtype=torch.bfloat16, device=x.device) if out is None else out
+        mask = torch.empty((B, 2 * Ho, 2 * Wo), dtype=torch.uint8, device=x.device)
+        y_cstride, y_coff = 4, 0
+    else:
+        if out_mode == OUT_PIXEL_SHUFFLE:
+            oshape = (B, 2 * Ho, 2 * Wo, Cout // 4)
+        elif out_mode == OUT_REPLICATE:
+            oshape = (B, out_f * Ho, out_f * Wo, Cout)
+        else:
+            oshape = (B, Ho, Wo, Cout)
+        if out is None:
+            y = torch.empty(oshape, dtype=out_dtype, device=x.device)
+            y_coff = 0
+        else:
+            y = out
+            assert tuple(y.shape[:3]) == oshape[:3] and y.is_contiguous() and y.dtype == out_dtype
+            assert out_coff + oshape[3] <= y.shape[3]
+            y_coff = out_coff
+        y_cstride = y.shape[3]
+    res_cstride = 0
+    if res is not None and res_mode != RES_NONE:
+        assert res.dtype == torch.bfloat16 and res.is_contiguous()
+        res_cstride = res.shape[3]
+        if res_mode == RES_SAME:
+            assert tuple(res.shape[:3]) == (B, Ho, Wo)
+        else:
+            assert tuple(res.shape[:3]) == (B, (Ho + 1) // 2, (Wo + 1) // 2)
+        assert res.shape[3] >= Cout
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() >= Cout and bias.is_contiguous()
+
+    rc = _loader.lib().dlamd_conv2d(
+        _loader.ptr(x), _loader.ptr(w), _loader.ptr(bias), _loader.ptr(res if res_mode != RES_NONE else None),
+        _loader.ptr(y), _loader.ptr(mask),
+        B, H, W, Cin, x_cstride, Cout, kh, kw, sh, sw, ph, pw,
+        ACT[act], res_mode, res_cstride, out_mode, out_f, y_cstride, y_coff,
+        1 if out_dtype == torch.float32 else 0, float(thr), cfg, _loader.stream_ptr(),
+    )
+    _loader.check(rc, "dlamd_conv2d")
+    if out_mode == OUT_PROB:
+        return y, mask
+    return y
+
+
+def linear_bf16(
+    x: torch.Tensor,
+    w: torch.Tensor,
+    bias: Optional[torch.Tensor] = None,
+    *,
+    act: str = "none",
+    res: Optional[torch.Tensor] = None,
+    out_dtype: torch.dtype = torch.bfloat16,
+) -> torch.Tensor:
+    """y = act(x @ w^T + bias (+ res)) through the 1x1 path of the conv kernel.
+
+    x: [..., K] bf16, w: [N, K] bf16, bias: [N] f32, res: [..., N] bf16.
+    """
+    lead = x.shape[:-1]
+    K = x.shape[-1]
+    N = w.shape[0]
+    x2 = x.reshape(1, 1, -1, K)
+    r2 = None if res is None else res.reshape(1, 1, -1, N)
+    y = conv2d_nhwc(
+        x2, w.view(N, 1, 1, K), bias, act=act, res=r2, res_mode=RES_SAME if res is not None else RES_NONE,
+        out_dtype=out_dtype,
+    )
+    return y.reshape(*lead, N)

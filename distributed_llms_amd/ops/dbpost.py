@@ -1,0 +1,159 @@
+"""DB post-processing: probability map -> text boxes.
+
+GPU path: ``dlamd_db_postprocess`` (csrc/kernels/db_postprocess.hip) -
+union-find connected components, per-component statistics and closed-form
+rectangle unclip, all on device; only the small box table crosses to the host.
+
+CPU path / oracle: ``db_postprocess_reference`` (scipy.ndimage.label with
+8-connectivity, same scoring / unclip arithmetic).
+
+The reference stack does this with OpenCV findContours + pyclipper + shapely
+(services/ocr_service/requirements.txt:160,200,271) inside magic-pdf.
+Thresholds default to the published DBNet values (binarise 0.3, box score
+0.6, unclip ratio 1.5) - see the provenance warning in SURVEY.md 2E.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _loader
+
+
+@dataclass
+class DBPostConfig:
+    bin_thresh: float = 0.3
+    box_thresh: float = 0.6
+    unclip_ratio: float = 1.5
+    min_size: int = 3
+    max_components: int = 4096
+    max_boxes: int = 1024
+
+
+def _finalize(stats, scale, valid, cfg: DBPostConfig, H: int, W: int) -> np.ndarray:
+    """Shared arithmetic of box_finalize_kernel for one page (numpy, float32)."""
+    out = []
+    sx, sy = (float(scale[0]), float(scale[1])) if scale is not None else (1.0, 1.0)
+    vw, vh = (int(valid[0]), int(valid[1])) if valid is not None else (W, H)
+    for (xmin, ymin, xmax, ymax, cnt, psum) in stats:
+        if cnt <= 0:
+            continue
+        score = np.float32(psum) / np.float32(cnt)
+        x0, y0, x1, y1 = np.float32(xmin), np.float32(ymin), np.float32(xmax + 1), np.float32(ymax + 1)
+        w, h = x1 - x0, y1 - y0
+        if min(w, h) < cfg.min_size or score < np.float32(cfg.box_thresh):
+            continue
+        d = (w * h) * np.float32(cfg.unclip_ratio) / (np.float32(2.0) * (w + h))
+        x0, y0 = max(x0 - d, np.float32(0)), max(y0 - d, np.float32(0))
+        x1, y1 = min(x1 + d, np.float32(vw)), min(y1 + d, np.float32(vh))
+        if x1 - x0 < cfg.min_size + 2 or y1 - y0 < cfg.min_size + 2:
+            continue
+        out.append([x0 * sx, y0 * sy, x1 * sx, y1 * sy, score, np.float32(cnt)])
+    return np.asarray(out, dtype=np.float32).reshape(-1, 6)
+
+
+def db_postprocess_reference(
+    prob: torch.Tensor, mask: torch.Tensor, cfg: DBPostConfig,
+    page_scale: Optional[torch.Tensor] = None, valid: Optional[torch.Tensor] = None,
+) -> List[np.ndarray]:
+    """prob [B,H,W] (any float), mask [B,H,W] u8 -> list of [n_i, 6] float32 box tables."""
+    from scipy import ndimage
+
+    B, H, W = mask.shape
+    pr = prob.float().cpu().numpy()
+    mk = mask.cpu().numpy() > 0
+    res = []
+    structure = np.ones((3, 3), dtype=bool)
+    for b in range(B):
+        lab, n = ndimage.label(mk[b], structure=structure)
+        stats = []
+        if n > 0:
+            objs = ndimage.find_objects(lab)
+            sums = ndimage.sum(pr[b], lab, index=np.arange(1, n + 1))
+            cnts = ndimage.sum(mk[b], lab, index=np.arange(1, n + 1))
+            for i, sl in enumerate(objs):
+                ys, xs = sl
+                stats.append((xs.start, ys.start, xs.stop - 1, ys.stop - 1, int(cnts[i]), float(sums[i])))
+        sc = None if page_scale is None else page_scale[b].cpu().numpy()
+        vd = None if valid is None else valid[b].cpu().numpy()
+        res.append(_finalize(stats, sc, vd, cfg, H, W))
+    return res
+
+
+class DBPostWorkspace:
+    """Device workspaces for a fixed (B, H, W); reused across batches (no allocs in the hot loop)."""
+
+    def __init__(self, B: int, H: int, W: int, cfg: DBPostConfig, device: torch.device):
+        self.B, self.H, self.W, self.cfg = B, H, W, cfg
+        self.parent = torch.empty((B, H, W), dtype=torch.int32, device=device)
+        self.comp_id = torch.empty((B, H, W), dtype=torch.int32, device=device)
+        self.stats = torch.empty((B, cfg.max_components, 6), dtype=torch.int32, device=device)
+        self.ncomp = torch.empty((B,), dtype=torch.int32, device=device)
+        self.nbox = torch.empty((B,), dtype=torch.int32, device=device)
+        self.boxes = torch.empty((B, cfg.max_boxes, 6), dtype=torch.float32, device=device)
+
+
+def db_postprocess_gpu(
+    prob: torch.Tensor, mask: torch.Tensor, ws: DBPostWorkspace,
+    page_scale: Optional[torch.Tensor] = None, valid: Optional[torch.Tensor] = None,
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Launch the device post-process.  Returns (boxes [B,max_boxes,6], nbox [B]) device tensors."""
+    B, H, W = mask.shape
+    assert B <= ws.B and (H, W) == (ws.H, ws.W)
+    assert prob.dtype == torch.bfloat16 and mask.dtype == torch.uint8
+    assert prob.is_contiguous() and mask.is_contiguous()
+    cfg = ws.cfg
+    if page_scale is not None:
+        assert page_scale.dtype == torch.float32 and page_scale.is_contiguous()
+    if valid is not None:
+        assert valid.dtype == torch.int32 and valid.is_contiguous()
+    rc = _loader.lib().dlamd_db_postprocess(
+        _loader.ptr(mask), _loader.ptr(prob), _loader.ptr(ws.parent), _loader.ptr(ws.comp_id),
+        _loader.ptr(ws.stats), _loader.ptr(ws.ncomp), _loader.ptr(ws.nbox),
+        _loader.ptr(page_scale), _loader.ptr(valid), _loader.ptr(ws.boxes),
+        B, H, W, cfg.max_components, cfg.max_boxes, cfg.box_thresh, cfg.unclip_ratio, cfg.min_size,
+        _loader.stream_ptr(),
+    )
+    _loader.check(rc, "dlamd_db_postprocess")
+    return ws.boxes, ws.nbox
+
+
+def sort_boxes_reading_order(boxes: np.ndarray, line_tol: float = 0.5) -> np.ndarray:
+    """Top-to-bottom, left-to-right.  Boxes whose vertical centres differ by less than
+    ``line_tol`` x median height are treated as the same text row."""
+    if boxes.shape[0] == 0:
+        return boxes
+    cy = 0.5 * (boxes[:, 1] + boxes[:, 3])
+    h = np.median(boxes[:, 3] - boxes[:, 1])
+    order = np.argsort(cy, kind="stable")
+    boxes = boxes[order]
+    cy = cy[order]
+    rows, start = [], 0
+    for i in range(1, len(boxes) + 1):
+        if i == len(boxes) or cy[i] - cy[start] > line_tol * h:
+            seg = boxes[start:i]
+            rows.append(seg[np.argsort(seg[:, 0], kind="stable")])
+            start = i
+    return np.concatenate(rows, axis=0)
+
+
+def db_postprocess(
+    prob: torch.Tensor, mask: torch.Tensor, cfg: DBPostConfig,
+    page_scale: Optional[torch.Tensor] = None, valid: Optional[torch.Tensor] = None,
+    ws: Optional[DBPostWorkspace] = None,
+) -> List[np.ndarray]:
+    """Boxes per page as host arrays in reading order."""
+    if not mask.is_cuda:
+        res = db_postprocess_reference(prob, mask, cfg, page_scale, valid)
+    else:
+        B, H, W = mask.shape
+        if ws is None:
+            ws = DBPostWorkspace(B, H, W, cfg, mask.device)
+        boxes, nbox = db_postprocess_gpu(prob, mask, ws, page_scale, valid)
+        nb = nbox[:B].cpu().numpy()
+        bx = boxes[:B].cpu().numpy()
+        res = [bx[b, : min(int(nb[b]), cfg.max_boxes)].copy() for b in range(B)]
+    return [sort_boxes_reading_order(r) for r in res]

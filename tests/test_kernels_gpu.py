@@ -1,0 +1,235 @@
+"""HIP kernel numerics vs plain PyTorch fp32 references (run on a real MI355X)."""
+import numpy as np
+import pytest
+import torch
+
+from distributed_llms_amd.ops import conv as C
+from distributed_llms_amd.ops import ctc, dbpost, lstm, resample
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _rand_bf16(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16)
+
+
+def _close(a, b, rtol=2e-2, atol=2e-2):
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = (err > tol).float().mean().item()
+    assert bad < 1e-3, f"mismatch fraction {bad:.4f}, max err {err.max().item():.4f}"
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad, act
+    (2, 37, 53, 8, 32, 3, 2, 1, "relu"),       # stem: Cin=8 (K=72, ragged K tile), odd sizes
+    (2, 40, 48, 32, 64, 3, 1, 1, "relu"),
+    (1, 33, 29, 64, 64, 3, 1, 1, "none"),
+    (2, 24, 20, 64, 128, 3, 2, 1, "hardswish"),
+    (1, 16, 24, 128, 256, 3, 1, 1, "relu"),
+    (1, 9, 11, 256, 512, 3, 2, 1, "relu"),
+    (2, 20, 28, 64, 256, 1, 1, 0, "none"),      # 1x1 lateral
+    (2, 20, 28, 64, 128, 1, 2, 0, "none"),      # 1x1 stride-2 shortcut
+    (1, 12, 40, 256, 16, 3, 1, 1, "sigmoid"),   # narrow N tile
+    (1, 8, 8, 512, 512, 3, 1, 1, "gelu"),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_matches_reference(case):
+    B, H, W, Cin, Cout, k, s, p, act = case
+    x = _rand_bf16(B, H, W, Cin, seed=1)
+    w = _rand_bf16(Cout, k, k, Cin, scale=(2.0 / (k * k * Cin)) ** 0.5, seed=2)
+    b = torch.randn(Cout, generator=torch.Generator().manual_seed(3)) * 0.1
+    ref = C.conv2d_nhwc_reference(x, w, b, stride=s, padding=p, act=act, out_dtype=torch.float32)
+    out = C.conv2d_nhwc(x.to(DEV), w.to(DEV), b.to(DEV), stride=s, padding=p, act=act)
+    assert out.shape == ref.shape
+    _close(out, ref)
+
+
+def test_conv_asymmetric_kernel_and_stride():
+    x = _rand_bf16(3, 6, 50, 256, seed=4)
+    w = _rand_bf16(256, 3, 3, 256, scale=0.03, seed=5)
+    ref = C.conv2d_nhwc_reference(x, w, None, stride=(2, 1), padding=(1, 1), act="relu", out_dtype=torch.float32)
+    out = C.conv2d_nhwc(x.to(DEV), w.to(DEV), None, stride=(2, 1), padding=(1, 1), act="relu")
+    _close(out, ref)
+    w2 = _rand_bf16(128, 3, 1, 256, scale=0.04, seed=6)
+    ref = C.conv2d_nhwc_reference(x[:, :3], w2, None, stride=1, padding=0, out_dtype=torch.float32)
+    out = C.conv2d_nhwc(x[:, :3].contiguous().to(DEV), w2.to(DEV), None, stride=1, padding=0)
+    assert out.shape == (3, 1, 50, 128)
+    _close(out, ref)
+
+
+def test_conv_residual_same_and_upsampled():
+    x = _rand_bf16(2, 20, 28, 64, seed=7)
+    w = _rand_bf16(64, 3, 3, 64, scale=0.06, seed=8)
+    r = _rand_bf16(2, 20, 28, 64, seed=9)
+    ref = C.conv2d_nhwc_reference(x, w, None, stride=1, padding=1, act="relu", res=r, res_mode=C.RES_SAME,
+                                  out_dtype=torch.float32)
+    out = C.conv2d_nhwc(x.to(DEV), w.to(DEV), None, stride=1, padding=1, act="relu", res=r.to(DEV),
+                        res_mode=C.RES_SAME)
+    _close(out, ref)
+    w1 = _rand_bf16(64, 1, 1, 64, scale=0.12, seed=10)
+    r2 = _rand_bf16(2, 10, 14, 64, seed=11)
+    ref = C.conv2d_nhwc_reference(x, w1, None, res=r2, res_mode=C.RES_UP2, out_dtype=torch.float32)
+    out = C.conv2d_nhwc(x.to(DEV), w1.to(DEV), None, res=r2.to(DEV), res_mode=C.RES_UP2)
+    _close(out, ref)
+
+
+def test_conv_store_modes():
+    x = _rand_bf16(2, 10, 14, 64, seed=12)
+    # pixel shuffle (deconv 2x2 s2): Cout = 4 * 64
+    w = _rand_bf16(256, 1, 1, 64, scale=0.12, seed=13)
+    b = torch.randn(256) * 0.1
+    ref = C.conv2d_nhwc_reference(x, w, b, act="relu", out_mode=C.OUT_PIXEL_SHUFFLE, out_dtype=torch.float32)
+    out = C.conv2d_nhwc(x.to(DEV), w.to(DEV), b.to(DEV), act="relu", out_mode=C.OUT_PIXEL_SHUFFLE)
+    assert out.shape == (2, 20, 28, 64)
+    _close(out, ref)
+    # replicate x4 into a concat buffer at channel offset 64
+    w3 = _rand_bf16(64, 3, 3, 64, scale=0.06, seed=14)
+    ref = C.conv2d_nhwc_reference(x, w3, None, padding=1, out_mode=C.OUT_REPLICATE, out_f=4, out_dtype=torch.float32)
+    cat = torch.zeros(2, 40, 56, 256, dtype=torch.bfloat16, device=DEV)
+    C.conv2d_nhwc(x.to(DEV), w3.to(DEV), None, padding=1, out_mode=C.OUT_REPLICATE, out_f=4, out=cat, out_coff=64)
+    _close(cat[..., 64:128], ref)
+    assert cat[..., :64].abs().max().item() == 0 and cat[..., 128:].abs().max().item() == 0
+    # probability map + bitmask
+    w4 = _rand_bf16(4, 1, 1, 64, scale=0.3, seed=15)
+    b4 = torch.randn(4) * 0.1
+    pref, mref = C.conv2d_nhwc_reference(x, w4, b4, act="sigmoid", out_mode=C.OUT_PROB, thr=0.3,
+                                         out_dtype=torch.float32)
+    p, m = C.conv2d_nhwc(x.to(DEV), w4.to(DEV), b4.to(DEV), act="sigmoid", out_mode=C.OUT_PROB, thr=0.3)
+    assert p.shape == (2, 20, 28) and m.shape == (2, 20, 28)
+    _close(p, pref, atol=1e-2)
+    agree = ((m.cpu() > 0) == (mref > 0)) | ((pref - 0.3).abs() < 1e-2)
+    assert bool(agree.all())
+
+
+def test_linear_f32_out_and_strided_input():
+    x = _rand_bf16(5, 37, 512, seed=16)
+    w = _rand_bf16(96, 512, scale=0.05, seed=17)
+    b = torch.randn(96)
+    ref = x.float() @ w.float().t() + b
+    out = C.linear_bf16(x.to(DEV), w.to(DEV), b.to(DEV), out_dtype=torch.float32)
+    assert out.dtype == torch.float32
+    _close(out, ref)
+    # channel-sliced input (pixel stride 128, Cin 64)
+    big = _rand_bf16(2, 12, 12, 128, seed=18).to(DEV)
+    xs = big[..., 64:]
+    w3 = _rand_bf16(32, 3, 3, 64, scale=0.06, seed=19)
+    ref = C.conv2d_nhwc_reference(xs.cpu().contiguous(), w3, None, padding=1, out_dtype=torch.float32)
+    out = C.conv2d_nhwc(xs, w3.to(DEV), None, padding=1)
+    _close(out, ref)
+
+
+def test_resample_pages_and_crops():
+    g = torch.Generator().manual_seed(0)
+    page = torch.randint(0, 256, (351, 248), dtype=torch.uint8, generator=g)
+    rgb = torch.randint(0, 256, (120, 200, 3), dtype=torch.uint8, generator=g)
+    regs = [
+        resample.Region(page, (0, 0, 248, 351), 128, 90),            # shrink ~2.7x (box filter)
+        resample.Region(rgb, (0, 0, 200, 120), 96, 160),             # shrink 1.25x
+        resample.Region(page, (10.5, 20.25, 200.0, 60.0), 48, 128),  # crop, mixed
+        resample.Region(rgb, (5, 5, 45, 25), 48, 96),                # enlarge (bilinear)
+        resample.Region(page, (30, 40, 70, 300), 48, 120, rot=1),    # tall box rotated
+    ]
+    ref = resample.resample_regions_reference(regs, 128, 160)
+    dregs = [resample.Region(r.image.to(DEV), r.box, r.out_h, r.out_w, r.rot) for r in regs]
+    out = resample.resample_regions(dregs, 128, 160)
+    assert out.shape == (5, 128, 160, 8)
+    _close(out, ref, rtol=1e-2, atol=2e-2)
+    assert out[..., 3:].abs().max().item() == 0
+
+
+def test_db_postprocess_matches_scipy():
+    g = torch.Generator().manual_seed(0)
+    B, H, W = 3, 160, 192
+    prob = torch.rand(B, H, W, generator=g) * 0.25
+    # paint text-line-like blobs plus diagonal touching blobs (8-connectivity) and noise
+    for b in range(B):
+        for k in range(6):
+            y0, x0 = 10 + 22 * k, 8 + 5 * k
+            prob[b, y0 : y0 + 9, x0 : x0 + 120 - 10 * k] = 0.7 + 0.25 * torch.rand(9, 120 - 10 * k, generator=g)
+        prob[b, 150:154, 10:14] = 0.9
+        prob[b, 154:158, 14:18] = 0.9   # touches diagonally
+        prob[b, 100:103, 170:190] = 0.45  # low score component (filtered by box_thresh)
+    prob = prob.to(torch.bfloat16)
+    mask = (prob.float() > 0.3).to(torch.uint8)
+    cfg = dbpost.DBPostConfig()
+    scale = torch.tensor([[2.5, 2.5], [1.0, 2.0], [3.0, 1.5]], dtype=torch.float32)
+    valid = torch.tensor([[W, H], [W, H], [W - 10, H - 4]], dtype=torch.int32)
+    ref = dbpost.db_postprocess(prob, mask, cfg, scale, valid)
+    out = dbpost.db_postprocess(prob.to(DEV), mask.to(DEV), cfg, scale.to(DEV), valid.to(DEV))
+    for r, o in zip(ref, out):
+        assert r.shape == o.shape and r.shape[0] >= 7
+        np.testing.assert_allclose(o[:, :4], r[:, :4], rtol=1e-5, atol=1e-3)
+        np.testing.assert_allclose(o[:, 4], r[:, 4], rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(o[:, 5], r[:, 5])
+
+
+def test_db_postprocess_random_noise_components():
+    g = torch.Generator().manual_seed(1)
+    prob = torch.rand(2, 96, 128, generator=g).to(torch.bfloat16)
+    mask = (prob.float() > 0.55).to(torch.uint8)
+    cfg = dbpost.DBPostConfig(box_thresh=0.0, min_size=1, max_components=8192, max_boxes=8192)
+    ref = dbpost.db_postprocess(prob, mask, cfg)
+    out = dbpost.db_postprocess(prob.to(DEV), mask.to(DEV), cfg)
+    for r, o in zip(ref, out):
+        assert r.shape == o.shape
+        # same multiset of boxes (ordering of equal-key boxes may differ)
+        rs = r[np.lexsort(r[:, :4].T[::-1])]
+        os_ = o[np.lexsort(o[:, :4].T[::-1])]
+        np.testing.assert_allclose(os_[:, :4], rs[:, :4], atol=1e-3)
+        np.testing.assert_allclose(os_[:, 5], rs[:, 5])
+
+
+@pytest.mark.parametrize("V,dtype", [(97, torch.bfloat16), (6624, torch.bfloat16), (50, torch.float32)])
+def test_ctc_greedy_decode(V, dtype):
+    g = torch.Generator().manual_seed(0)
+    N, T = 7, 83
+    logits = (torch.randn(N, T, V, generator=g) * 3).to(dtype)
+    # force repeats and blanks
+    logits[:, 10:14, 5] += 30
+    logits[:, 20:25, 0] += 30
+    lens = torch.tensor([83, 80, 1, 0, 40, 83, 13], dtype=torch.int32)
+    ref_ids, ref_len, ref_conf = ctc.ctc_greedy_reference(logits, lens)
+    ids, ln, conf = ctc.ctc_greedy_decode(logits.to(DEV), lens.to(DEV))
+    assert torch.equal(ln.cpu(), ref_len)
+    assert torch.equal(ids.cpu(), ref_ids)
+    torch.testing.assert_close(conf.cpu(), ref_conf, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("H,ndir", [(256, 2), (128, 2), (64, 1)])
+def test_lstm_matches_reference(H, ndir):
+    torch.manual_seed(0)
+    N, T, I = 21, 19, 96
+    w_ih = [torch.randn(4 * H, I) * 0.1 for _ in range(ndir)]
+    w_hh = [torch.randn(4 * H, H) * 0.06 for _ in range(ndir)]
+    b_ih = [torch.randn(4 * H) * 0.1 for _ in range(ndir)]
+    b_hh = [torch.randn(4 * H) * 0.1 for _ in range(ndir)]
+    # round weights to bf16 so the oracle sees the same parameters
+    w_ih = [w.to(torch.bfloat16).float() for w in w_ih]
+    w_hh = [w.to(torch.bfloat16).float() for w in w_hh]
+    p = lstm.pack_lstm_weights(w_ih, w_hh, b_ih, b_hh)
+    x = (torch.randn(N, T, I) * 0.8).to(torch.bfloat16)
+    lens = torch.randint(1, T + 1, (N,), dtype=torch.int32)
+    lens[0] = T
+    ref = lstm.lstm_reference(x, p, lens)
+    out = lstm.lstm_layer(x.to(DEV), p.to(DEV), lens.to(DEV))
+    assert out.shape == ref.shape
+    _close(out, ref, rtol=3e-2, atol=3e-2)
+    # matches torch.nn.LSTM on full-length sequences too
+    m = torch.nn.LSTM(I, H, batch_first=True, bidirectional=(ndir == 2))
+    with torch.no_grad():
+        for d in range(ndir):
+            sfx = "_reverse" if d == 1 else ""
+            getattr(m, "weight_ih_l0" + sfx).copy_(w_ih[d])
+            getattr(m, "weight_hh_l0" + sfx).copy_(w_hh[d])
+            getattr(m, "bias_ih_l0" + sfx).copy_(b_ih[d])
+            getattr(m, "bias_hh_l0" + sfx).copy_(b_hh[d])
+        ref2, _ = m(x.float())
+    out2 = lstm.lstm_layer(x.to(DEV), p.to(DEV), None)
+    _close(out2, ref2, rtol=3e-2, atol=3e-2)
