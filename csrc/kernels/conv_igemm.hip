@@ -266,7 +266,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
             long long pix = ((long long)b * H2 + 2 * ho + dy) * W2 + 2 * wo;
             bf16x2 pr = {(bf16_t)v[dy * 2], (bf16_t)v[dy * 2 + 1]};
             *reinterpret_cast<bf16x2*>(yp + pix) = pr;
-            uint16_t mk = uint16_t(v[dy * 2] > p.thr ? 1 : 0) | uint16_t((v[dy * 2 + 1] > p.thr ? 1 : 0) << 8);
+            // threshold the ROUNDED value so mask and stored probability always agree
+            uint16_t mk = uint16_t((float)pr[0] > p.thr ? 1 : 0) | uint16_t(((float)pr[1] > p.thr ? 1 : 0) << 8);
             *reinterpret_cast<uint16_t*>(p.mask + pix) = mk;
           }
         }

@@ -1,0 +1,149 @@
+"""CRNN line recognizer: conv stack -> 2 x BiLSTM(256) -> Linear -> CTC.
+
+Input crops are ``[N, 48, W, 8]`` NHWC bf16 (3 real channels), W a bucket width
+(multiple of 32).  The conv stack reduces height 48 -> 1 and width by 4, so
+T = W / 4 time steps; each sample carries its own valid length
+ceil(valid_w / 4) which the persistent LSTM kernel and the CTC decoder honour.
+
+Inference path: 6 MFMA implicit-GEMM convs, per LSTM layer one projection GEMM
++ one persistent recurrent kernel, one FC GEMM, CTC greedy decode - 13 kernel
+launches per batch, captured in one hipGraph per (batch, width) bucket by the
+runtime.
+
+Training path (``forward``): the same parameters through PyTorch autograd
+(nn.LSTM / MIOpen), used by train/ with the HIP CTC loss and fused AdamW.
+
+Reference: the recognizer there is PaddleOCR-torch's rec model fetched by
+services/ocr_service/download_models_hf.py:41 and run on CPU inside magic-pdf.
+"""
+from __future__ import annotations
+
+import string
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from ..ops import ctc as ctc_ops
+from ..ops import lstm as lstm_ops
+from ..ops.conv import linear_bf16
+from .layers import ConvBNAct, prepare_all
+
+# 95 printable ASCII characters; vocabulary index 0 is the CTC blank.
+DEFAULT_CHARSET = "".join(chr(c) for c in range(32, 127))
+
+
+class CRNN(nn.Module):
+    def __init__(self, charset: str = DEFAULT_CHARSET, hidden: int = 256, height: int = 48,
+                 widths=(64, 128, 256, 256, 512, 512)):
+        super().__init__()
+        assert height == 48, "conv stack is laid out for 48-pixel-high crops"
+        self.charset = charset
+        self.num_classes = len(charset) + 1
+        self.vocab_padded = (self.num_classes + 3) // 4 * 4
+        self.height, self.hidden = height, hidden
+        c1, c2, c3, c4, c5, c6 = widths
+        self.convs = nn.ModuleList([
+            ConvBNAct(3, c1, 3, 2),                      # 24 x W/2
+            ConvBNAct(c1, c2, 3, 2),                     # 12 x W/4
+            ConvBNAct(c2, c3, 3, 1),                     # 12 x W/4
+            ConvBNAct(c3, c4, 3, (2, 1)),                # 6  x W/4
+            ConvBNAct(c4, c5, 3, (2, 1)),                # 3  x W/4
+            ConvBNAct(c5, c6, (3, 1), 1, padding=(0, 0)),  # 1  x W/4
+        ])
+        self.rnn1 = nn.LSTM(c6, hidden, batch_first=True, bidirectional=True)
+        self.rnn2 = nn.LSTM(2 * hidden, hidden, batch_first=True, bidirectional=True)
+        self.fc = nn.Linear(2 * hidden, self.num_classes)
+        self._packed = None
+
+    @staticmethod
+    def time_steps(width: int) -> int:
+        return width // 4
+
+    @staticmethod
+    def valid_steps(valid_w: torch.Tensor) -> torch.Tensor:
+        return torch.div(valid_w + 3, 4, rounding_mode="floor").clamp(min=1)
+
+    # ------------------------------------------------------------------ training path
+    def forward(self, x: torch.Tensor, lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x: [N,3,48,W] -> logits [N, T, num_classes] (fp32)."""
+        y = x
+        for c in self.convs:
+            y = c(y)
+        y = y.squeeze(2).transpose(1, 2)  # [N, T, C]
+        if lens is not None:
+            packed = nn.utils.rnn.pack_padded_sequence(y, lens.cpu().long(), batch_first=True, enforce_sorted=False)
+            o, _ = self.rnn1(packed)
+            o, _ = self.rnn2(o)
+            y, _ = nn.utils.rnn.pad_packed_sequence(o, batch_first=True, total_length=y.shape[1])
+        else:
+            y, _ = self.rnn1(y)
+            y, _ = self.rnn2(y)
+        return self.fc(y)
+
+    # ------------------------------------------------------------------ inference path
+    def prepare(self) -> "CRNN":
+        self.eval()
+        prepare_all(self)
+        dev = self.fc.weight.device
+
+        def pack(m: nn.LSTM) -> lstm_ops.PackedLSTM:
+            return lstm_ops.pack_lstm_weights(
+                [m.weight_ih_l0.detach(), m.weight_ih_l0_reverse.detach()],
+                [m.weight_hh_l0.detach(), m.weight_hh_l0_reverse.detach()],
+                [m.bias_ih_l0.detach(), m.bias_ih_l0_reverse.detach()],
+                [m.bias_hh_l0.detach(), m.bias_hh_l0_reverse.detach()],
+            ).to(dev)
+
+        fw = torch.zeros(self.vocab_padded, self.fc.in_features, device=dev)
+        fw[: self.num_classes] = self.fc.weight.detach().float()
+        fb = torch.full((self.vocab_padded,), -1e4, device=dev)  # padded classes can never win the argmax
+        fb[: self.num_classes] = self.fc.bias.detach().float()
+        self._packed = (pack(self.rnn1), pack(self.rnn2), fw.to(torch.bfloat16).contiguous(), fb.contiguous())
+        return self
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    @torch.no_grad()
+    def infer_logits(self, x: torch.Tensor, lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x: [N,48,W,8] bf16 -> logits [N, T, vocab_padded] bf16."""
+        if self._packed is None:
+            self.prepare()
+        r1, r2, fw, fb = self._packed
+        y = x
+        for c in self.convs:
+            y = c.infer(y)
+        N, _, T, Cc = y.shape
+        y = y.reshape(N, T, Cc)
+        y = lstm_ops.lstm_layer(y, r1, lens)
+        y = lstm_ops.lstm_layer(y, r2, lens)
+        return linear_bf16(y, fw, fb)
+
+    @torch.no_grad()
+    def infer(self, x: torch.Tensor, lens: Optional[torch.Tensor] = None
+              ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """-> (ids [N,T] int32 padded -1, lengths [N] int32, confidence [N] f32)."""
+        logits = self.infer_logits(x, lens)
+        return ctc_ops.ctc_greedy_decode(logits, lens, blank=0)
+
+    def decode_strings(self, ids: torch.Tensor, lens: torch.Tensor) -> List[str]:
+        return ctc_ops.ids_to_strings(ids, lens, self.charset)
+
+    def encode_text(self, text: str) -> List[int]:
+        idx = {c: i + 1 for i, c in enumerate(self.charset)}
+        return [idx[c] for c in text if c in idx]
+
+    def flops_per_crop(self, W: int) -> float:
+        def conv(cin, cout, kh, kw, h, w):
+            return 2.0 * cin * cout * kh * kw * h * w
+
+        ch = [c.cout for c in self.convs]
+        T = W // 4
+        f = conv(8, ch[0], 3, 3, 24, W // 2) + conv(ch[0], ch[1], 3, 3, 12, T) + conv(ch[1], ch[2], 3, 3, 12, T)
+        f += conv(ch[2], ch[3], 3, 3, 6, T) + conv(ch[3], ch[4], 3, 3, 3, T) + conv(ch[4], ch[5], 3, 1, 1, T)
+        H = self.hidden
+        f += 2.0 * T * (ch[5] * 8 * H + 2 * H * 8 * H) + 2.0 * T * 2 * (2 * H * 4 * H)  # projections + recurrences
+        f += 2.0 * T * 2 * H * self.vocab_padded
+        return f

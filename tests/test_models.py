@@ -1,0 +1,93 @@
+"""Model parity: fused NHWC inference path vs plain PyTorch NCHW path (same parameters)."""
+import pytest
+import torch
+
+from distributed_llms_amd.models.crnn import CRNN
+from distributed_llms_amd.models.dbnet import DBNet
+
+
+def _randomize_bn(model):
+    g = torch.Generator().manual_seed(0)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) * 0.5 + 0.75)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) * 0.5 + 0.75)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+
+
+def _nhwc8(x):
+    B, C, H, W = x.shape
+    out = torch.zeros(B, H, W, 8, dtype=x.dtype)
+    out[..., :C] = x.permute(0, 2, 3, 1)
+    return out
+
+
+def test_dbnet_infer_matches_forward_cpu():
+    torch.manual_seed(0)
+    net = DBNet(widths=(16, 32, 32, 64), stem=8, inner=32).eval()
+    _randomize_bn(net)
+    x = torch.randn(2, 3, 64, 96)
+    with torch.no_grad():
+        ref = net(x)
+    prob, mask = net.infer(_nhwc8(x).to(torch.bfloat16))
+    assert prob.shape == (2, 64, 96) and mask.shape == (2, 64, 96) and mask.dtype == torch.uint8
+    # bf16 activations between layers in the oracle path -> loose tolerance
+    err = (prob.float() - ref).abs()
+    assert err.mean().item() < 0.01 and err.max().item() < 0.25
+
+
+def test_crnn_infer_matches_forward_cpu():
+    torch.manual_seed(0)
+    net = CRNN(hidden=64, widths=(16, 32, 32, 32, 64, 64)).eval()
+    _randomize_bn(net)
+    x = torch.randn(3, 3, 48, 64) * 0.5
+    lens = torch.tensor([16, 9, 3], dtype=torch.int32)
+    with torch.no_grad():
+        ref = net(x, lens)
+    logits = net.infer_logits(_nhwc8(x).to(torch.bfloat16), lens).float()
+    assert logits.shape == (3, 16, net.vocab_padded)
+    for n in range(3):
+        L = int(lens[n])
+        assert (logits[n, :L, : net.num_classes] - ref[n, :L]).abs().max().item() < 0.08
+    ids, ln, conf = net.infer(_nhwc8(x).to(torch.bfloat16), lens)
+    assert ids.shape == (3, 16) and (ln <= lens).all()
+    strs = net.decode_strings(ids, ln)
+    assert len(strs) == 3 and all(isinstance(s, str) for s in strs)
+    assert net.encode_text("Hi!") == [ord("H") - 31, ord("i") - 31, ord("!") - 31]
+
+
+@pytest.mark.gpu
+def test_dbnet_gpu_matches_cpu_oracle():
+    torch.manual_seed(0)
+    net = DBNet().eval()
+    _randomize_bn(net)
+    x = (torch.randn(2, 3, 96, 160) * 0.7)
+    x8 = _nhwc8(x).to(torch.bfloat16)
+    ref_prob, _ = net.infer(x8)
+    net = net.to("cuda").prepare()
+    prob, mask = net.infer(x8.to("cuda"))
+    torch.cuda.synchronize()
+    err = (prob.float().cpu() - ref_prob.float()).abs()
+    assert err.max().item() < 0.06, err.max().item()
+    assert err.mean().item() < 0.01
+    assert bool(((mask.cpu() > 0) == (prob.cpu().float() > net.bin_thresh)).all())
+
+
+@pytest.mark.gpu
+def test_crnn_gpu_matches_cpu_oracle():
+    torch.manual_seed(0)
+    net = CRNN().eval()
+    _randomize_bn(net)
+    x = (torch.randn(5, 3, 48, 160) * 0.5)
+    lens = torch.tensor([40, 33, 17, 40, 1], dtype=torch.int32)
+    x8 = _nhwc8(x).to(torch.bfloat16)
+    ref = net.infer_logits(x8, lens).float()
+    net = net.to("cuda").prepare()
+    out = net.infer_logits(x8.to("cuda"), lens.to("cuda")).float().cpu()
+    for n in range(5):
+        L = int(lens[n])
+        d = (out[n, :L] - ref[n, :L]).abs()
+        assert d.max().item() < 0.15, (n, d.max().item())
+    ids, ln, conf = net.infer(x8.to("cuda"), lens.to("cuda"))
+    assert ids.shape == (5, 40) and bool((ln.cpu() <= lens).all())
