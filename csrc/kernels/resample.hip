@@ -20,7 +20,8 @@ struct ResampleItem {
   int rot;              // 0 none, 1 = rotate region 90 deg ccw into output
   float x0, y0, x1, y1; // source region (pixels, half-open, may be fractional)
   int out_h, out_w;     // valid output size (<= Hd, Wd)
-  int pad0, pad1;
+  int pitch;            // source row pitch in bytes (0: Ws * C)
+  int pad1;
 };
 static_assert(sizeof(ResampleItem) == 56, "ResampleItem layout is part of the Python ABI");
 
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(256) void resample_kernel(const ResampleItem* __res
   float acc[3] = {0.f, 0.f, 0.f};
   const int C = it.C;
   const uint8_t* src = it.src;
+  const long long pitch = it.pitch > 0 ? it.pitch : (long long)it.Ws * C;
   if (su > 1.f || sv > 1.f) {
     // fractional box filter over [lo, hi)
     float xlo = it.x0 + u * su, xhi = xlo + su;
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void resample_kernel(const ResampleItem* __res
     for (int y = ya; y < yb; ++y) {
       float wy = fminf(yhi, (float)(y + 1)) - fmaxf(ylo, (float)y);
       wy = fmaxf(wy, 1e-6f);
-      const uint8_t* row = src + (long long)y * it.Ws * C;
+      const uint8_t* row = src + (long long)y * pitch;
       for (int x = xa; x < xb; ++x) {
         float wx = fminf(xhi, (float)(x + 1)) - fmaxf(xlo, (float)x);
         wx = fmaxf(wx, 1e-6f);
@@ -95,8 +97,8 @@ __global__ __launch_bounds__(256) void resample_kernel(const ResampleItem* __res
     int xa = (int)floorf(sx), ya = (int)floorf(sy);
     int xb = min(xa + 1, it.Ws - 1), yb = min(ya + 1, it.Hs - 1);
     float fx = sx - xa, fy = sy - ya;
-    const uint8_t* r0 = src + (long long)ya * it.Ws * C;
-    const uint8_t* r1 = src + (long long)yb * it.Ws * C;
+    const uint8_t* r0 = src + (long long)ya * pitch;
+    const uint8_t* r1 = src + (long long)yb * pitch;
     for (int ch = 0; ch < C; ++ch) {
       float a = r0[xa * C + ch], b = r0[xb * C + ch], c2 = r1[xa * C + ch], d = r1[xb * C + ch];
       acc[ch] = (a * (1.f - fx) + b * fx) * (1.f - fy) + (c2 * (1.f - fx) + d * fx) * fy;

@@ -27,7 +27,7 @@ ITEM_DTYPE = np.dtype(
     [
         ("src", "<u8"), ("Hs", "<i4"), ("Ws", "<i4"), ("C", "<i4"), ("rot", "<i4"),
         ("x0", "<f4"), ("y0", "<f4"), ("x1", "<f4"), ("y1", "<f4"),
-        ("out_h", "<i4"), ("out_w", "<i4"), ("pad0", "<i4"), ("pad1", "<i4"),
+        ("out_h", "<i4"), ("out_w", "<i4"), ("pitch", "<i4"), ("pad1", "<i4"),
     ],
     align=False,
 )
@@ -145,11 +145,14 @@ def pack_items(regions: Sequence[Region]) -> np.ndarray:
     items = np.zeros(len(regions), dtype=ITEM_DTYPE)
     for n, r in enumerate(regions):
         img = r.image
-        assert img.dtype == torch.uint8 and img.is_contiguous()
+        assert img.dtype == torch.uint8
         Hs, Ws = img.shape[0], img.shape[1]
         C = 1 if img.dim() == 2 else img.shape[2]
         assert C in (1, 3)
-        items[n] = (img.data_ptr(), Hs, Ws, C, r.rot, r.box[0], r.box[1], r.box[2], r.box[3], r.out_h, r.out_w, 0, 0)
+        # rows may be pitched (e.g. a [:H, :W] view of a JPEG plane padded to whole MCUs); pixels must be packed
+        assert img.stride(1) == C and (img.dim() == 2 or img.stride(2) == 1), "pixels must be densely packed in a row"
+        items[n] = (img.data_ptr(), Hs, Ws, C, r.rot, r.box[0], r.box[1], r.box[2], r.box[3], r.out_h, r.out_w,
+                    img.stride(0), 0)
     return items
 
 

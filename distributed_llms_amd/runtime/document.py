@@ -1,0 +1,225 @@
+"""Document-level extraction: PDF bytes -> combined text (call stack 3.2).
+
+This is the MI355X-native ``process_pdf_sync`` (services/ocr_service/ocr_service.py:201-255):
+
+    PymuDocDataset(bytes)         -> pdf.reader.PdfDocument (C++)
+    ds.classify()                 -> PdfDocument.classify()            TXT | OCR
+    apply(doc_analyze, ocr=True)  -> OcrEngine (HIP kernels) over page batches
+    pipe_txt_mode                 -> native text-operator extraction
+    get_content_list / markdown   -> ``content_list`` of {'type': 'text', 'text': ..., 'page_idx': n}
+    join 'text' with "\\n\\n"       -> ``combine_text`` (same rule, same markdown fallback)
+
+Page images reach the GPU in the cheapest form available: baseline JPEGs with
+restart markers are shipped compressed and decoded by the GPU kernel; other
+JPEGs go through libjpeg-turbo and Flate images through the native inflater on
+a host thread pool that runs ahead of the GPU by two batches.
+"""
+from __future__ import annotations
+
+import os
+import re
+import time
+from concurrent.futures import Future, ThreadPoolExecutor
+from dataclasses import dataclass, field
+from typing import Dict, Iterator, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from ..ops import jpeg as jpeg_ops
+from ..pdf import reader
+from .engine import OcrEngine, PageImage, PageResult, StageTimer, TextLine, _to_gray
+
+
+class ExtractionError(RuntimeError):
+    pass
+
+
+@dataclass
+class DocumentResult:
+    document_id: str
+    mode: str                                   # "txt" | "ocr"
+    pages: List[PageResult] = field(default_factory=list)
+    content_list: List[dict] = field(default_factory=list)
+    markdown: str = ""
+    text: str = ""
+    timings: Dict[str, float] = field(default_factory=dict)
+
+
+_MD_HEADER = re.compile(r"#+\s+")
+_MD_MARKS = re.compile(r"\*\*|\*|__|\||---|___")
+
+
+def combine_text(content_list: Sequence, markdown: str = "") -> str:
+    """The reference's combined-text rule (ocr_service.py:229-248)."""
+    out = ""
+    for item in content_list:
+        if isinstance(item, dict) and "text" in item:
+            out += item["text"] + "\n\n"
+        elif isinstance(item, str):
+            out += item + "\n\n"
+    if not out.strip():
+        clean = _MD_HEADER.sub("", markdown or "")
+        clean = _MD_MARKS.sub("", clean)
+        out = clean
+    return out.strip()
+
+
+def lines_to_paragraphs(lines: Sequence[TextLine]) -> List[str]:
+    """Group recognised lines (already in reading order) into paragraphs by vertical gaps."""
+    paras: List[List[str]] = []
+    prev: Optional[TextLine] = None
+    for ln in lines:
+        if not ln.text.strip():
+            continue
+        new = prev is None
+        if prev is not None:
+            h = max(1.0, min(prev.box[3] - prev.box[1], ln.box[3] - ln.box[1]))
+            gap = ln.box[1] - prev.box[3]
+            same_row = abs((ln.box[1] + ln.box[3]) - (prev.box[1] + prev.box[3])) * 0.5 < 0.5 * h
+            new = not same_row and (gap > 0.8 * h or abs((ln.box[3] - ln.box[1]) - (prev.box[3] - prev.box[1])) > 0.35 * h)
+        if new:
+            paras.append([ln.text.strip()])
+        else:
+            paras[-1].append(ln.text.strip())
+        prev = ln
+    return [" ".join(p) for p in paras]
+
+
+def build_content_list(pages: Sequence[PageResult]) -> List[dict]:
+    items = []
+    for pg in pages:
+        for para in lines_to_paragraphs(pg.lines):
+            items.append({"type": "text", "text": para, "page_idx": pg.page_index})
+    return items
+
+
+class DocumentPipeline:
+    def __init__(self, engine: OcrEngine, decode_threads: Optional[int] = None, prefetch_batches: int = 2,
+                 ocr_dpi: int = 300):
+        self.engine = engine
+        n = decode_threads or min(16, max(2, (os.cpu_count() or 4) // max(1, torch.cuda.device_count() or 1)))
+        self.pool = ThreadPoolExecutor(max_workers=n, thread_name_prefix="dlamd-decode")
+        self.prefetch = prefetch_batches
+        self.timer = StageTimer()
+        self.ocr_dpi = ocr_dpi
+
+    def close(self) -> None:
+        self.pool.shutdown(wait=False, cancel_futures=True)
+
+    # ------------------------------------------------------------------ page sources
+    def _load_page(self, doc: reader.PdfDocument, i: int, doc_id: str, prior) -> Optional[PageImage]:
+        """Runs on the decode pool.  Returns None for pages without an image (text layer is used instead)."""
+        im = doc.main_image(i)
+        if im is None:
+            return None
+        if im.codec == reader.CODEC_JPEG:
+            stream = doc.jpeg_bytes(im)
+            scan = reader.scan_jpeg(stream)
+            if scan.gpu_decodable and self.engine.on_gpu:
+                return PageImage(None, doc_id, i, prior, encoded=(stream, scan))
+            arr = _to_gray(jpeg_ops.decode_jpeg_host(stream))
+        elif im.codec == reader.CODEC_RAW:
+            shape = (im.height, im.width) if im.out_channels == 1 else (im.height, im.width, 3)
+            if self.engine.on_gpu:
+                t = torch.empty(shape, dtype=torch.uint8, pin_memory=True)
+                doc.decode_image(im, t.numpy())
+                return PageImage(t, doc_id, i, prior)
+            arr = doc.decode_image(im)
+        else:
+            raise ExtractionError(f"page {i}: unsupported image encoding")
+        t = torch.from_numpy(arr)
+        if self.engine.on_gpu:
+            t = t.pin_memory()
+        return PageImage(t, doc_id, i, prior)
+
+    def _page_batches(self, doc, page_ids, doc_id, priors, skipped: List[int]) -> Iterator[List[PageImage]]:
+        B = self.engine.cfg.max_batch_pages
+        chunks = [page_ids[k : k + B] for k in range(0, len(page_ids), B)]
+        futs: List[List[Future]] = []
+
+        def submit(c):
+            return [self.pool.submit(self._load_page, doc, i, doc_id, None if priors is None else priors[i]) for i in c]
+
+        nxt = 0
+        while nxt < len(chunks) and nxt < self.prefetch:
+            futs.append(submit(chunks[nxt]))
+            nxt += 1
+        for k in range(len(chunks)):
+            t0 = time.perf_counter()
+            pages = []
+            for i, f in zip(chunks[k], futs[k]):
+                p = f.result()
+                if p is None:
+                    skipped.append(i)
+                else:
+                    pages.append(p)
+            self.timer.add("wait_decode", time.perf_counter() - t0)
+            if nxt < len(chunks):
+                futs.append(submit(chunks[nxt]))
+                nxt += 1
+            yield pages
+
+    # ------------------------------------------------------------------ entry points
+    def process_pdf(self, pdf_bytes: bytes, document_id: str = "", layout_priors=None,
+                    force_mode: Optional[str] = None) -> DocumentResult:
+        t0 = time.perf_counter()
+        try:
+            doc = reader.PdfDocument(pdf_bytes)
+        except reader.PdfError as e:
+            raise ExtractionError(f"cannot parse PDF: {e}") from e
+        try:
+            cls = doc.classify()
+            mode = force_mode or ("txt" if cls.is_text else "ocr")
+            t1 = time.perf_counter()
+            self.timer.add("parse", t1 - t0)
+            res = DocumentResult(document_id, mode)
+            n = doc.page_count
+            if n == 0:
+                raise ExtractionError("PDF has no pages")
+            if mode == "txt":
+                for i in range(n):
+                    txt = doc.page_text(i)
+                    for para in txt.split("\n\n"):
+                        para = " ".join(s.strip() for s in para.split("\n") if s.strip())
+                        if para:
+                            res.content_list.append({"type": "text", "text": para, "page_idx": i})
+            else:
+                skipped: List[int] = []
+                pages: List[PageResult] = []
+                for batch_res in self.engine.process_batches(
+                        self._page_batches(doc, list(range(n)), document_id, layout_priors, skipped)):
+                    pages.extend(batch_res)
+                # pages without any image: fall back to whatever text layer they have
+                for i in skipped:
+                    pi = doc.page_info(i)
+                    pr = PageResult(document_id, i, int(pi.width_pt), int(pi.height_pt))
+                    txt = doc.page_text(i, include_invisible=True)
+                    y = 0.0
+                    for para in txt.split("\n\n"):
+                        para = " ".join(s.strip() for s in para.split("\n") if s.strip())
+                        if para:
+                            pr.lines.append(TextLine((0.0, y, 1.0, y + 1.0), para, 1.0))
+                            y += 3.0
+                    pages.append(pr)
+                pages.sort(key=lambda p: p.page_index)
+                res.pages = pages
+                res.content_list = build_content_list(pages)
+            res.markdown = "\n\n".join(it["text"] for it in res.content_list)
+            res.text = combine_text(res.content_list, res.markdown)
+            res.timings = {"total_s": time.perf_counter() - t0, "parse_s": t1 - t0}
+            return res
+        finally:
+            doc.close()
+
+    def process_rasters(self, images: Sequence[torch.Tensor], document_id: str = "", layout_priors=None
+                        ) -> DocumentResult:
+        """Already-decoded page rasters (uint8 tensors) -> DocumentResult (OCR branch only)."""
+        pages_in = [PageImage(img, document_id, i, None if layout_priors is None else layout_priors[i])
+                    for i, img in enumerate(images)]
+        res = DocumentResult(document_id, "ocr")
+        res.pages = self.engine.process_pages(pages_in)
+        res.content_list = build_content_list(res.pages)
+        res.markdown = "\n\n".join(it["text"] for it in res.content_list)
+        res.text = combine_text(res.content_list, res.markdown)
+        return res
