@@ -23,7 +23,8 @@ __global__ __launch_bounds__(256) void row_argmax_kernel(const T* __restrict__ l
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= R) return;
   const T* p = logits + row * row_stride;
-  float m = -INFINITY, s = 0.f;
+  // finite sentinel: the library is built with -ffast-math (no infinities); idle lanes carry (m = -1e30, s = 0)
+  float m = -1e30f, s = 0.f;
   int am = 0;
   if (sizeof(T) == 2 && (V % 8 == 0) && (row_stride % 8 == 0)) {
     const u32x4* pv = reinterpret_cast<const u32x4*>(p);
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void row_argmax_kernel(const T* __restrict__ l
     int oa = __shfl_xor(am, o, 64);
     float os = __shfl_xor(s, o, 64);
     float nm = fmaxf(m, om);
-    float ns = (m == -INFINITY ? 0.f : s * __expf(m - nm)) + (om == -INFINITY ? 0.f : os * __expf(om - nm));
+    float ns = s * __expf(m - nm) + os * __expf(om - nm);
     if (om > m || (om == m && oa < am)) am = oa;
     m = nm; s = ns;
   }
@@ -68,7 +69,9 @@ __global__ __launch_bounds__(256) void row_argmax_kernel(const T* __restrict__ l
 
 // idx/prob: [N, T]; lens: [N] valid time steps (or nullptr -> T); out_ids: [N, T] (padded with -1)
 __global__ __launch_bounds__(256) void ctc_collapse_kernel(const int* __restrict__ idx, const float* __restrict__ prob,
-                                                           const int* __restrict__ lens, int* __restrict__ out_ids,
+                                                           const int* __restrict__ lens,
+                                                           const long long* __restrict__ row_off,
+                                                           int* __restrict__ out_ids,
                                                            int* __restrict__ out_len, float* __restrict__ out_conf,
                                                            int T, int blank) {
   __shared__ int s_cnt[256];
@@ -78,8 +81,10 @@ __global__ __launch_bounds__(256) void ctc_collapse_kernel(const int* __restrict
   const int len = lens ? min(lens[n], T) : T;
   const int per = (T + 255) / 256;
   const int t0 = tid * per, t1 = min(t0 + per, len);
-  const int* row = idx + (long long)n * T;
-  const float* prow = prob + (long long)n * T;
+  // ragged input: sequence n starts at row_off[n] of the packed idx / prob vectors (output stays [N, T])
+  const long long in0 = row_off ? row_off[n] : (long long)n * T;
+  const int* row = idx + in0;
+  const float* prow = prob + in0;
   int cnt = 0;
   float ps = 0.f;
   for (int t = t0; t < t1; ++t) {
@@ -128,11 +133,13 @@ extern "C" int dlamd_row_argmax(const void* logits, int is_f32, void* idx, void*
   return DLAMD_CHECK_LAUNCH();
 }
 
-extern "C" int dlamd_ctc_collapse(const void* idx, const void* prob, const void* lens, void* out_ids, void* out_len,
-                                  void* out_conf, int N, int T, int blank, hipStream_t stream) {
+extern "C" int dlamd_ctc_collapse(const void* idx, const void* prob, const void* lens, const void* row_off,
+                                  void* out_ids, void* out_len, void* out_conf, int N, int T, int blank,
+                                  hipStream_t stream) {
   if (N <= 0) return 0;
   if (T <= 0) return -1;
+  if (row_off && !lens) return -2;
   hipLaunchKernelGGL(ctc_collapse_kernel, dim3(N), dim3(256), 0, stream, (const int*)idx, (const float*)prob,
-                     (const int*)lens, (int*)out_ids, (int*)out_len, (float*)out_conf, T, blank);
+                     (const int*)lens, (const long long*)row_off, (int*)out_ids, (int*)out_len, (float*)out_conf, T, blank);
   return DLAMD_CHECK_LAUNCH();
 }

@@ -16,13 +16,26 @@
 // in one lane.  Gate rows are laid out as r = tile*16 + fq*4 + gate with
 // unit(tile, fq) = (tile/4)*16 + fq*4 + tile%4, so four consecutive tiles give
 // a lane four consecutive hidden units -> 8-byte packed h stores.
+#include <stdlib.h>
+
 #include "common.h"
+
+// exp-based activations on the hardware exp unit (v_exp_f32): 1 exp + 1 rcp each
+__device__ __forceinline__ float dl_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float dl_tanh(float x) {
+  float e = __expf(-2.f * fabsf(x));
+  float t = (1.f - e) * __frcp_rn(1.f + e);
+  return copysignf(t, x);
+}
 
 template <int H>
 __global__ __launch_bounds__(256) void lstm_bidir_kernel(const bf16_t* __restrict__ xproj,   // [N, T, ndir*4H] permuted cols
                                                          const bf16_t* __restrict__ wfrag,   // [ndir][4H/16][H/32][64][8]
                                                          const int* __restrict__ lens,       // [N] or nullptr
-                                                         bf16_t* __restrict__ y,             // [N, T, ndir*H]
+                                                         const long long* __restrict__ row_off,  // [N] first row of each sequence (ragged) or nullptr
+                                                         const int* __restrict__ tcap,       // [N] allocated steps per sequence (ragged) or nullptr
+                                                         const int* __restrict__ perm,       // [N] slot -> sequence (length-sorted scheduling) or nullptr
+                                                         bf16_t* __restrict__ y,             // [N, T, ndir*H] (or packed rows)
                                                          int N, int T, int ndir) {
   constexpr int G = 4 * H;            // gate columns
   constexpr int TILES = G / 16 / 4;   // row tiles per wave
@@ -33,9 +46,12 @@ __global__ __launch_bounds__(256) void lstm_bidir_kernel(const bf16_t* __restric
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int seq_l = lane & 15, fq = lane >> 4;
   const int dir = blockIdx.y;
-  const int n = blockIdx.x * 16 + seq_l;
-  const bool seq_ok = n < N;
-  const int len = seq_ok ? (lens ? min(lens[n], T) : T) : 0;
+  const int slot = blockIdx.x * 16 + seq_l;
+  const bool seq_ok = slot < N;
+  const int n = seq_ok ? (perm ? perm[slot] : slot) : 0;
+  const int cap = seq_ok ? (tcap ? tcap[n] : T) : 0;
+  const int len = seq_ok ? (lens ? min(lens[n], cap) : cap) : 0;
+  const long long row0 = seq_ok ? (row_off ? row_off[n] : (long long)n * T) : 0;
   // longest sequence in this workgroup
   int maxlen = len;
 #pragma unroll
@@ -47,8 +63,8 @@ __global__ __launch_bounds__(256) void lstm_bidir_kernel(const bf16_t* __restric
   const bf16_t* wf = wfrag + (long long)dir * G * H + (long long)wave * TILES * KS * 64 * 8 + lane * 8;
   const long long xrow = (long long)ndir * G;       // elements per (n, t) row of xproj
   const long long yrow = (long long)ndir * H;
-  const bf16_t* xp = xproj + (long long)(seq_ok ? n : 0) * T * xrow + (long long)dir * G + (wave * TILES) * 16 + fq * 4;
-  bf16_t* yp = y + (long long)(seq_ok ? n : 0) * T * yrow + (long long)dir * H;
+  const bf16_t* xp = xproj + row0 * xrow + (long long)dir * G + (wave * TILES) * 16 + fq * 4;
+  bf16_t* yp = y + row0 * yrow + (long long)dir * H;
 
   float cst[TILES];
 #pragma unroll
@@ -57,6 +73,10 @@ __global__ __launch_bounds__(256) void lstm_bidir_kernel(const bf16_t* __restric
   for (int step = 0; step < maxlen; ++step) {
     const int cur = step & 1;
     const bool act = step < len;
+    // W_hh does not depend on the step, so LICM would hoist all 128 fragment loads out of the loop and
+    // spill them (208 VGPRs of scratch); laundering the pointer keeps the loads inside the step.
+    const bf16_t* wfs = wf;
+    asm volatile("" : "+v"(wfs));
     const int t = dir == 0 ? step : (len - 1 - step);
     // gate pre-activations from the input projection
     f32x4 acc[TILES];
@@ -78,7 +98,7 @@ __global__ __launch_bounds__(256) void lstm_bidir_kernel(const bf16_t* __restric
       bf16x8 w[KS];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
-        w[ks] = *reinterpret_cast<const bf16x8*>(wf + (long long)(i * KS + ks) * 64 * 8);
+        w[ks] = *reinterpret_cast<const bf16x8*>(wfs + (long long)(i * KS + ks) * 64 * 8);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
         acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks], hf[ks], acc[i], 0, 0, 0);
@@ -113,7 +133,7 @@ __global__ __launch_bounds__(256) void lstm_bidir_kernel(const bf16_t* __restric
   }
   // zero the padded tail of y so downstream GEMMs see clean rows
   if (seq_ok) {
-    for (int t = len; t < T; ++t)
+    for (int t = len; t < cap; ++t)
 #pragma unroll
       for (int a = 0; a < TILES / 4; ++a) {
         const int unit = (wave * (TILES / 4) + a) * 16 + fq * 4;
@@ -122,22 +142,237 @@ __global__ __launch_bounds__(256) void lstm_bidir_kernel(const bf16_t* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v2 (throughput shape): 8 waves per workgroup and ST x 16 sequences per workgroup.
+// The recurrence is bound by streaming W_hh (2*H*4H bytes per direction) from L2 once per step per
+// workgroup, so (a) ST sequence tiles share every W fragment (half / quarter the workgroups and the
+// L2 traffic for the same batch), (b) 8 waves keep twice as many loads in flight per CU, and (c) the
+// K loop is outermost with the next K-group's W fragments prefetched while the current group's
+// MFMAs run (W does not depend on h, so the prefetch also wraps across the step boundary).
+template <int H, int ST>
+__global__ __launch_bounds__(512) void lstm_bidir_kernel2(const bf16_t* __restrict__ xproj, const bf16_t* __restrict__ wfrag,
+                                                          const int* __restrict__ lens,
+                                                          const long long* __restrict__ row_off,
+                                                          const int* __restrict__ tcap, const int* __restrict__ perm,
+                                                          bf16_t* __restrict__ y, int N, int T, int ndir) {
+  constexpr int G = 4 * H;
+  constexpr int NW = 8;
+  constexpr int TILES = G / 16 / NW;
+  constexpr int KS = H / 32;
+  constexpr int HROW = H * 2 + 16;
+  constexpr int SEQ = 16 * ST;
+  static_assert(TILES % 4 == 0, "a lane needs 4 consecutive tiles per hidden-unit group");
+  extern __shared__ __attribute__((aligned(16))) char hbuf_dyn[];
+  char* hb0 = hbuf_dyn;
+  char* hb1 = hbuf_dyn + SEQ * HROW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int seq_l = lane & 15, fq = lane >> 4;
+  const int dir = blockIdx.y;
+  const long long xrow = (long long)ndir * G;
+  const long long yrow = (long long)ndir * H;
+
+  int len[ST], cap[ST];
+  bool ok[ST];
+  const bf16_t* xp[ST];
+  bf16_t* yp[ST];
+  int maxlen = 0;
+#pragma unroll
+  for (int st = 0; st < ST; ++st) {
+    const int slot = blockIdx.x * SEQ + st * 16 + seq_l;
+    ok[st] = slot < N;
+    const int n = ok[st] ? (perm ? perm[slot] : slot) : 0;
+    cap[st] = ok[st] ? (tcap ? tcap[n] : T) : 0;
+    len[st] = ok[st] ? (lens ? min(lens[n], cap[st]) : cap[st]) : 0;
+    const long long row0 = ok[st] ? (row_off ? row_off[n] : (long long)n * T) : 0;
+    xp[st] = xproj + row0 * xrow + (long long)dir * G + (wave * TILES) * 16 + fq * 4;
+    yp[st] = y + row0 * yrow + (long long)dir * H;
+    maxlen = max(maxlen, len[st]);
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
+
+  for (int i = tid; i < 2 * SEQ * HROW / 4; i += 512) reinterpret_cast<uint32_t*>(hbuf_dyn)[i] = 0u;
+  __syncthreads();
+
+  const bf16_t* wf = wfrag + (long long)dir * G * H + (long long)wave * TILES * KS * 64 * 8 + lane * 8;
+  float cst[TILES][ST];
+#pragma unroll
+  for (int i = 0; i < TILES; ++i)
+#pragma unroll
+    for (int st = 0; st < ST; ++st) cst[i][st] = 0.f;
+
+  bf16x8 wa[TILES], wb[TILES];
+#pragma unroll
+  for (int i = 0; i < TILES; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(wf + (long long)(i * KS) * 64 * 8);
+  // gate pre-activations of the CURRENT step (loaded one step ahead: they come from HBM)
+  u32x2 xc[TILES][ST], xn[TILES][ST];
+#pragma unroll
+  for (int st = 0; st < ST; ++st) {
+    const int t0 = dir == 0 ? 0 : (len[st] - 1);
+#pragma unroll
+    for (int i = 0; i < TILES; ++i) {
+      xc[i][st] = u32x2{0u, 0u};
+      if (len[st] > 0) xc[i][st] = *reinterpret_cast<const u32x2*>(xp[st] + (long long)t0 * xrow + i * 16);
+    }
+  }
+
+  for (int step = 0; step < maxlen; ++step) {
+    const char* hc = (step & 1) ? hb1 : hb0;
+    char* hn = (step & 1) ? hb0 : hb1;
+    const bf16_t* wfs = wf;          // see v1: keep the W loads inside the step loop
+    asm volatile("" : "+v"(wfs));
+    f32x4 acc[TILES][ST];
+    bool act[ST];
+    int tt[ST];
+#pragma unroll
+    for (int st = 0; st < ST; ++st) {
+      act[st] = step < len[st];
+      tt[st] = dir == 0 ? step : (len[st] - 1 - step);
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) acc[i][st] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ks += 2) {
+      // even group computes from wa while wb (ks + 1) is in flight, and vice versa
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) wb[i] = *reinterpret_cast<const bf16x8*>(wfs + (long long)(i * KS + ks + 1) * 64 * 8);
+      {
+        bf16x8 hf[ST];
+#pragma unroll
+        for (int st = 0; st < ST; ++st)
+          hf[st] = *reinterpret_cast<const bf16x8*>(hc + (st * 16 + seq_l) * HROW + ks * 64 + fq * 16);
+#pragma unroll
+        for (int i = 0; i < TILES; ++i)
+#pragma unroll
+          for (int st = 0; st < ST; ++st) acc[i][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[i], hf[st], acc[i][st], 0, 0, 0);
+      }
+      const int kn = (ks + 2) % KS;  // wraps to the first group of the next step
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(wfs + (long long)(i * KS + kn) * 64 * 8);
+      if (ks == KS - 2) {
+        // last loads of the step: next step's pre-activations.  Issued after every W load of this step so
+        // that (in-order vmcnt) no W wait of this step has to cover their HBM latency.
+#pragma unroll
+        for (int st = 0; st < ST; ++st) {
+          const bool nact = step + 1 < len[st];
+          const int tn = dir == 0 ? step + 1 : (len[st] - 2 - step);
+#pragma unroll
+          for (int i = 0; i < TILES; ++i) {
+            xn[i][st] = u32x2{0u, 0u};
+            if (nact) xn[i][st] = *reinterpret_cast<const u32x2*>(xp[st] + (long long)tn * xrow + i * 16);
+          }
+        }
+      }
+      {
+        bf16x8 hf[ST];
+#pragma unroll
+        for (int st = 0; st < ST; ++st)
+          hf[st] = *reinterpret_cast<const bf16x8*>(hc + (st * 16 + seq_l) * HROW + (ks + 1) * 64 + fq * 16);
+#pragma unroll
+        for (int i = 0; i < TILES; ++i)
+#pragma unroll
+          for (int st = 0; st < ST; ++st) acc[i][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[i], hf[st], acc[i][st], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int st = 0; st < ST; ++st) {
+#pragma unroll
+      for (int a = 0; a < TILES / 4; ++a) {
+        bf16x4 hv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = a * 4 + q;
+          const u32x2 raw = xc[i][st];
+          float ig = dl_sigmoid(acc[i][st][0] + bf16_bits_to_f32(raw[0] & 0xffffu));
+          float fg = dl_sigmoid(acc[i][st][1] + bf16_bits_to_f32(raw[0] >> 16));
+          float gg = dl_tanh(acc[i][st][2] + bf16_bits_to_f32(raw[1] & 0xffffu));
+          float og = dl_sigmoid(acc[i][st][3] + bf16_bits_to_f32(raw[1] >> 16));
+          float c = fg * cst[i][st] + ig * gg;
+          float h = og * dl_tanh(c);
+          if (act[st]) cst[i][st] = c;
+          hv[q] = (bf16_t)h;
+        }
+        const int unit = (wave * (TILES / 4) + a) * 16 + fq * 4;
+        const int hoff = (st * 16 + seq_l) * HROW + unit * 2;
+        if (act[st]) {
+          *reinterpret_cast<bf16x4*>(hn + hoff) = hv;
+          *reinterpret_cast<bf16x4*>(yp[st] + (long long)tt[st] * yrow + unit) = hv;
+        } else {
+          *reinterpret_cast<u32x2*>(hn + hoff) = *reinterpret_cast<const u32x2*>(hc + hoff);
+        }
+      }
+    }
+#pragma unroll
+    for (int st = 0; st < ST; ++st)
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) xc[i][st] = xn[i][st];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int st = 0; st < ST; ++st) {
+    if (!ok[st]) continue;
+    for (int t = len[st]; t < cap[st]; ++t)
+#pragma unroll
+      for (int a = 0; a < TILES / 4; ++a) {
+        const int unit = (wave * (TILES / 4) + a) * 16 + fq * 4;
+        *reinterpret_cast<u32x2*>(yp[st] + (long long)t * yrow + unit) = u32x2{0u, 0u};
+      }
+  }
+}
+
+template <int H, int ST>
+static int launch_lstm2(const void* xproj, const void* wfrag, const void* lens, const void* row_off, const void* tcap,
+                        const void* perm, void* y, int N, int T, int ndir, hipStream_t stream) {
+  constexpr int SEQ = 16 * ST;
+  const size_t smem = 2 * SEQ * (H * 2 + 16);
+  auto k = lstm_bidir_kernel2<H, ST>;
+  if (smem > 65536 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    return -5;
+  dim3 grid((N + SEQ - 1) / SEQ, ndir);
+  hipLaunchKernelGGL(k, grid, dim3(512), smem, stream, (const bf16_t*)xproj, (const bf16_t*)wfrag, (const int*)lens,
+                     (const long long*)row_off, (const int*)tcap, (const int*)perm, (bf16_t*)y, N, T, ndir);
+  return DLAMD_CHECK_LAUNCH();
+}
+
 // xproj: [N, T, ndir*4H] bf16 with gate columns in the permuted order (see
 // ops/lstm.py: lstm_gate_permutation); wfrag: fragment-ordered W_hh per direction.
-extern "C" int dlamd_lstm_bidir(const void* xproj, const void* wfrag, const void* lens, void* y, int N, int T, int H,
-                                int ndir, hipStream_t stream) {
+static int variant_env() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DLAMD_LSTM_VARIANT"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
+// Ragged mode: row_off / tcap (and optionally perm) describe sequences packed back to back as rows of xproj / y.
+extern "C" int dlamd_lstm_bidir(const void* xproj, const void* wfrag, const void* lens, const void* row_off,
+                                const void* tcap, const void* perm, void* y, int N, int T, int H, int ndir,
+                                hipStream_t stream) {
   if (N <= 0 || T <= 0) return 0;
   if (ndir < 1 || ndir > 2) return -1;
+  if ((row_off == nullptr) != (tcap == nullptr)) return -3;
+  if (row_off && !lens) return -4;
+  // Shape selection: v1 (4 waves x 16 sequences) minimises latency for small batches; v2 (8 waves,
+  // 32 sequences) halves W_hh traffic per sequence once there are enough sequences to fill CUs anyway.
+  // DLAMD_LSTM_VARIANT (benchmarks only): 1 = v1, 2 = v2 with 16 sequences, 3 = v2 with 32 sequences.
+  const int var = variant_env();
+  // Measured on MI355X (us per step, H=256, both directions): N=970: v1 10.5, v2x16 7.5, v2x32 10.0;
+  // N=4000: v2x16 16.4, v2x32 13.1 -> 8-wave kernel everywhere, 32 sequences once CUs are oversubscribed.
+  const int var = variant_env();
+  if (H == 256 && (var == 3 || (var == 0 && N >= 3072)))
+    return launch_lstm2<256, 2>(xproj, wfrag, lens, row_off, tcap, perm, y, N, T, ndir, stream);
+  if (H == 256 && (var == 2 || (var == 0 && N >= 64)))
+    return launch_lstm2<256, 1>(xproj, wfrag, lens, row_off, tcap, perm, y, N, T, ndir, stream);
   dim3 grid((N + 15) / 16, ndir);
   if (H == 256)
     hipLaunchKernelGGL(lstm_bidir_kernel<256>, grid, dim3(256), 0, stream, (const bf16_t*)xproj, (const bf16_t*)wfrag,
-                       (const int*)lens, (bf16_t*)y, N, T, ndir);
+                       (const int*)lens, (const long long*)row_off, (const int*)tcap, (const int*)perm, (bf16_t*)y, N, T, ndir);
   else if (H == 128)
     hipLaunchKernelGGL(lstm_bidir_kernel<128>, grid, dim3(256), 0, stream, (const bf16_t*)xproj, (const bf16_t*)wfrag,
-                       (const int*)lens, (bf16_t*)y, N, T, ndir);
+                       (const int*)lens, (const long long*)row_off, (const int*)tcap, (const int*)perm, (bf16_t*)y, N, T, ndir);
   else if (H == 64)
     hipLaunchKernelGGL(lstm_bidir_kernel<64>, grid, dim3(256), 0, stream, (const bf16_t*)xproj, (const bf16_t*)wfrag,
-                       (const int*)lens, (bf16_t*)y, N, T, ndir);
+                       (const int*)lens, (const long long*)row_off, (const int*)tcap, (const int*)perm, (bf16_t*)y, N, T, ndir);
   else
     return -2;
   return DLAMD_CHECK_LAUNCH();

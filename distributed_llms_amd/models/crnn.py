@@ -128,6 +128,36 @@ class CRNN(nn.Module):
         logits = self.infer_logits(x, lens)
         return ctc_ops.ctc_greedy_decode(logits, lens, blank=0)
 
+    @torch.no_grad()
+    def infer_ragged(self, xs: List[torch.Tensor], lay: "lstm_ops.RaggedLayout"
+                     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Recognise crops of several width buckets in one pass.
+
+        xs[b]: [N_b, 48, W_b, 8] bf16.  The conv stack runs per bucket (it needs a uniform width) and
+        writes its [N_b, T_b, C] features straight into one packed [R, C] row matrix; everything after
+        it - both LSTM layers (input GEMM + ONE persistent recurrent launch each), the classifier GEMM
+        and the CTC decode - runs once over all buckets, so the sequential recurrence sees every crop
+        of the batch at the same time instead of one under-filled launch per bucket.
+        ``lay`` describes the packing (sequence order = concatenation order of ``xs``)."""
+        if self._packed is None:
+            self.prepare()
+        r1, r2, fw, fb = self._packed
+        C6 = self.convs[-1].cout
+        feat = torch.empty((lay.rows, C6), dtype=torch.bfloat16, device=xs[0].device)
+        r0 = 0
+        for x in xs:
+            y = x
+            for c in self.convs[:-1]:
+                y = c.infer(y)
+            N, T = x.shape[0], x.shape[2] // 4
+            self.convs[-1].infer(y, out=feat[r0 : r0 + N * T].view(N, 1, T, C6))
+            r0 += N * T
+        assert r0 == lay.rows
+        y = lstm_ops.lstm_layer_ragged(feat, r1, lay)
+        y = lstm_ops.lstm_layer_ragged(y, r2, lay)
+        logits = linear_bf16(y, fw, fb)
+        return ctc_ops.ctc_greedy_decode_ragged(logits, lay.lens, lay.row_off, lay.tmax, blank=0)
+
     def decode_strings(self, ids: torch.Tensor, lens: torch.Tensor) -> List[str]:
         return ctc_ops.ids_to_strings(ids, lens, self.charset)
 

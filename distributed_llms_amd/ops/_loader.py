@@ -81,8 +81,8 @@ def _declare(l: ctypes.CDLL) -> None:
     sig("dlamd_resample", [vp, i, vp, i, i, f, f, f, f, f, f, vp])
     sig("dlamd_db_postprocess", [vp] * 10 + [i, i, i, i, i, f, f, i, vp])
     sig("dlamd_row_argmax", [vp, i, vp, vp, ll, i, ll, vp])
-    sig("dlamd_ctc_collapse", [vp, vp, vp, vp, vp, vp, i, i, i, vp])
-    sig("dlamd_lstm_bidir", [vp, vp, vp, vp, i, i, i, i, vp])
+    sig("dlamd_ctc_collapse", [vp, vp, vp, vp, vp, vp, vp, i, i, i, vp])
+    sig("dlamd_lstm_bidir", [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, vp])
     sig("dlamd_layernorm", [vp, vp, vp, vp, vp, ll, i, f, i, vp])
     sig("dlamd_attention_fwd", [vp, vp, vp, vp, vp, i, i, i, i, i, ll, ll, ll, ll, f, i, vp])
     sig("dlamd_ctc_loss", [vp, i, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp])

@@ -78,8 +78,36 @@ def ctc_greedy_decode(
     if lens is not None:
         assert lens.dtype == torch.int32 and lens.is_cuda
     rc = _loader.lib().dlamd_ctc_collapse(
-        _loader.ptr(idx), _loader.ptr(prob), _loader.ptr(lens), _loader.ptr(out), _loader.ptr(out_len),
+        _loader.ptr(idx), _loader.ptr(prob), _loader.ptr(lens), None, _loader.ptr(out), _loader.ptr(out_len),
         _loader.ptr(conf), N, T, blank, _loader.stream_ptr(),
+    )
+    _loader.check(rc, "dlamd_ctc_collapse")
+    return out, out_len, conf
+
+
+def ctc_greedy_decode_ragged(logits: torch.Tensor, lens: torch.Tensor, row_off: torch.Tensor, tmax: int,
+                             blank: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """logits: [R, V] packed rows; sequence n occupies rows row_off[n] .. row_off[n] + lens[n].
+    -> (ids [N, tmax] padded -1, lengths [N], confidence [N])."""
+    N = lens.shape[0]
+    if not logits.is_cuda:
+        out = torch.full((N, tmax), -1, dtype=torch.int32)
+        out_len = torch.zeros((N,), dtype=torch.int32)
+        conf = torch.zeros((N,), dtype=torch.float32)
+        for n in range(N):
+            r0, L = int(row_off[n]), int(lens[n])
+            o, ol, c = ctc_greedy_reference(logits[r0 : r0 + L].unsqueeze(0), None, blank)
+            out[n, :L] = o[0]
+            out_len[n], conf[n] = ol[0], c[0]
+        return out, out_len, conf
+    idx, prob = row_argmax(logits)
+    out = torch.empty((N, tmax), dtype=torch.int32, device=logits.device)
+    out_len = torch.empty((N,), dtype=torch.int32, device=logits.device)
+    conf = torch.empty((N,), dtype=torch.float32, device=logits.device)
+    assert lens.dtype == torch.int32 and row_off.dtype == torch.int64 and lens.is_cuda and row_off.is_cuda
+    rc = _loader.lib().dlamd_ctc_collapse(
+        _loader.ptr(idx), _loader.ptr(prob), _loader.ptr(lens), _loader.ptr(row_off), _loader.ptr(out),
+        _loader.ptr(out_len), _loader.ptr(conf), N, tmax, blank, _loader.stream_ptr(),
     )
     _loader.check(rc, "dlamd_ctc_collapse")
     return out, out_len, conf

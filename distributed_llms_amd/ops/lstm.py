@@ -111,7 +111,51 @@ def lstm_layer(x: torch.Tensor, p: PackedLSTM, lens: Optional[torch.Tensor] = No
     if lens is not None:
         assert lens.dtype == torch.int32 and lens.is_cuda
     rc = _loader.lib().dlamd_lstm_bidir(
-        _loader.ptr(xproj), _loader.ptr(p.w_frag), _loader.ptr(lens), _loader.ptr(y), N, T, p.H, p.ndir,
+        _loader.ptr(xproj), _loader.ptr(p.w_frag), _loader.ptr(lens), None, None, None, _loader.ptr(y), N, T, p.H,
+        p.ndir, _loader.stream_ptr(),
+    )
+    _loader.check(rc, "dlamd_lstm_bidir")
+    return y
+
+
+@dataclass
+class RaggedLayout:
+    """Sequences of different allocated lengths packed back to back as rows of one [R, C] matrix.
+
+    ``row_off[n]`` = first row of sequence n, ``tcap[n]`` = rows allocated to it, ``lens[n]`` = valid
+    steps (<= tcap), ``perm`` = slot -> sequence order used to schedule workgroups (longest first, so
+    the 16 sequences sharing a workgroup have similar lengths)."""
+
+    row_off: torch.Tensor   # int64 [N]
+    tcap: torch.Tensor      # int32 [N]
+    lens: torch.Tensor      # int32 [N]
+    perm: torch.Tensor      # int32 [N]
+    rows: int
+    tmax: int
+
+    @property
+    def n(self) -> int:
+        return int(self.lens.shape[0])
+
+
+def lstm_layer_ragged(x: torch.Tensor, p: PackedLSTM, lay: RaggedLayout) -> torch.Tensor:
+    """x: [R, I] bf16 packed rows -> [R, ndir*H] bf16; ONE recurrent launch for every width bucket."""
+    if not x.is_cuda:
+        out = torch.zeros(x.shape[0], p.ndir * p.H, dtype=x.dtype)
+        ro, tc, ln = lay.row_off.tolist(), lay.tcap.tolist(), lay.lens.tolist()
+        for n in range(lay.n):
+            seg = x[ro[n] : ro[n] + tc[n]].unsqueeze(0)
+            y = lstm_reference(seg, p, torch.tensor([ln[n]]))
+            out[ro[n] : ro[n] + tc[n]] = y[0].to(x.dtype)
+        return out
+    assert x.dim() == 2 and x.is_contiguous()
+    xproj = linear_bf16(x, p.w_ih, p.bias)
+    y = torch.empty((x.shape[0], p.ndir * p.H), dtype=torch.bfloat16, device=x.device)
+    assert lay.row_off.dtype == torch.int64 and lay.tcap.dtype == torch.int32 and lay.lens.dtype == torch.int32
+    assert lay.perm.dtype == torch.int32 and lay.row_off.is_cuda
+    rc = _loader.lib().dlamd_lstm_bidir(
+        _loader.ptr(xproj), _loader.ptr(p.w_frag), _loader.ptr(lay.lens), _loader.ptr(lay.row_off),
+        _loader.ptr(lay.tcap), _loader.ptr(lay.perm), _loader.ptr(y), lay.n, lay.tmax, p.H, p.ndir,
         _loader.stream_ptr(),
     )
     _loader.check(rc, "dlamd_lstm_bidir")

@@ -35,6 +35,7 @@ from ..models.crnn import CRNN
 from ..models.dbnet import DBNet
 from ..ops import dbpost
 from ..ops import jpeg as jpeg_ops
+from ..ops import lstm as lstm_ops
 from ..ops import resample as rs
 
 
@@ -296,38 +297,83 @@ class OcrEngine:
         Ps = np.array([s.stride(0) for s in db.srcs], dtype=np.int32)
         ctx = torch.cuda.stream(db.stream) if self.on_gpu else _null_ctx()
         used_graphs: set = set()
+        lens_all = np.maximum((out_w + 3) // 4, 1).astype(np.int32)
         with ctx:
-            for wb in np.unique(bucket[idx_all]):
-                sel = idx_all[bucket[idx_all] == wb]
-                for c0 in range(0, sel.size, cfg.rec_max_batch):
-                    ids = sel[c0 : c0 + cfg.rec_max_batch]
-                    n = ids.size
-                    if self.on_gpu:
-                        items = np.zeros(n, dtype=rs.ITEM_DTYPE)
-                        pg = page_of[ids]
-                        items["src"], items["Hs"], items["Ws"], items["C"] = ptrs[pg], Hs[pg], Ws[pg], Cs[pg]
-                        items["rot"] = rot[ids]
-                        items["pitch"] = Ps[pg]
-                        items["x0"], items["y0"] = boxes[ids, 0], boxes[ids, 1]
-                        items["x1"], items["y1"] = boxes[ids, 2], boxes[ids, 3]
-                        items["out_h"], items["out_w"] = cfg.rec_height, out_w[ids]
-                        lens_np = np.maximum((out_w[ids] + 3) // 4, 1).astype(np.int32)
-                        out = self._rec_gpu(items, lens_np, int(wb), db.slot, used_graphs)
-                    else:
-                        regions = [
-                            rs.Region(db.srcs[page_of[i]], tuple(float(v) for v in boxes[i]), cfg.rec_height,
-                                      int(out_w[i]), int(rot[i])) for i in ids
-                        ]
-                        x = rs.resample_regions(regions, cfg.rec_height, int(wb), rs.HALF_MEAN, rs.HALF_STD)
-                        lens = torch.from_numpy(np.maximum((out_w[ids] + 3) // 4, 1).astype(np.int32))
-                        out = self.rec.infer(x, lens)
-                    rb.groups.append((ids, out))
+            buckets = [(int(wb), idx_all[bucket[idx_all] == wb]) for wb in np.unique(bucket[idx_all])]
+            small = cfg.use_hip_graphs and idx_all.size <= 2 * cfg.graph_max_crops
+            if self.on_gpu and not small:
+                # throughput regime: every bucket of the batch in ONE ragged recognition pass
+                rb.groups.append(self._rec_gpu_ragged(buckets, boxes, page_of, rot, out_w, lens_all,
+                                                      (ptrs, Hs, Ws, Cs, Ps)))
+            else:
+                for wb, sel in buckets:
+                    for c0 in range(0, sel.size, cfg.rec_max_batch):
+                        ids = sel[c0 : c0 + cfg.rec_max_batch]
+                        if self.on_gpu:
+                            items = self._crop_items(ids, boxes, page_of, rot, out_w, (ptrs, Hs, Ws, Cs, Ps))
+                            out = self._rec_gpu(items, lens_all[ids], wb, db.slot, used_graphs)
+                        else:
+                            regions = [
+                                rs.Region(db.srcs[page_of[i]], tuple(float(v) for v in boxes[i]), cfg.rec_height,
+                                          int(out_w[i]), int(rot[i])) for i in ids
+                            ]
+                            x = rs.resample_regions(regions, cfg.rec_height, wb, rs.HALF_MEAN, rs.HALF_STD)
+                            out = self.rec.infer(x, torch.from_numpy(lens_all[ids]))
+                        rb.groups.append((ids, out))
             if self.on_gpu:
                 rb.event = torch.cuda.Event()
                 rb.event.record(db.stream)
             else:
                 rb.event = None
         return rb
+
+    def _crop_items(self, ids, boxes, page_of, rot, out_w, src) -> np.ndarray:
+        ptrs, Hs, Ws, Cs, Ps = src
+        items = np.zeros(ids.size, dtype=rs.ITEM_DTYPE)
+        pg = page_of[ids]
+        items["src"], items["Hs"], items["Ws"], items["C"] = ptrs[pg], Hs[pg], Ws[pg], Cs[pg]
+        items["rot"] = rot[ids]
+        items["pitch"] = Ps[pg]
+        items["x0"], items["y0"] = boxes[ids, 0], boxes[ids, 1]
+        items["x1"], items["y1"] = boxes[ids, 2], boxes[ids, 3]
+        items["out_h"], items["out_w"] = self.cfg.rec_height, out_w[ids]
+        return items
+
+    def _rec_gpu_ragged(self, buckets, boxes, page_of, rot, out_w, lens_all, src):
+        """One upload (crop table + ragged layout), per-bucket crop kernels, one ragged CRNN pass, one D2H."""
+        cfg = self.cfg
+        order = np.concatenate([sel for _, sel in buckets])
+        n = order.size
+        items = self._crop_items(order, boxes, page_of, rot, out_w, src)
+        tcap = np.concatenate([np.full(sel.size, wb // 4, dtype=np.int32) for wb, sel in buckets])
+        lens = np.minimum(lens_all[order], tcap).astype(np.int32)
+        row_off = (np.cumsum(tcap, dtype=np.int64) - tcap).astype(np.int64)
+        perm = np.argsort(-lens, kind="stable").astype(np.int32)
+        rows, tmax = int(tcap.sum()), int(tcap.max())
+        blob = np.concatenate([row_off.view(np.uint8), items.view(np.uint8).reshape(-1), lens.view(np.uint8),
+                               tcap.view(np.uint8), perm.view(np.uint8)])
+        host = torch.from_numpy(blob).pin_memory()
+        dev = host.to(self.device, non_blocking=True)
+        o = 0
+        row_off_d = dev[o : o + 8 * n].view(torch.int64); o += 8 * n
+        items_d = dev[o : o + 56 * n]; o += 56 * n
+        lens_d = dev[o : o + 4 * n].view(torch.int32); o += 4 * n
+        tcap_d = dev[o : o + 4 * n].view(torch.int32); o += 4 * n
+        perm_d = dev[o : o + 4 * n].view(torch.int32)
+        xs, c0 = [], 0
+        for wb, sel in buckets:
+            xs.append(rs.resample_items_gpu(items_d[56 * c0 : 56 * (c0 + sel.size)], sel.size, cfg.rec_height, wb,
+                                            rs.HALF_MEAN, rs.HALF_STD))
+            c0 += sel.size
+        lay = lstm_ops.RaggedLayout(row_off_d, tcap_d, lens_d, perm_d, rows, tmax)
+        ids, ln, conf = self.rec.infer_ragged(xs, lay)
+        h_ids = torch.empty((n, tmax), dtype=torch.int32, pin_memory=True)
+        h_ln = torch.empty((n,), dtype=torch.int32, pin_memory=True)
+        h_cf = torch.empty((n,), dtype=torch.float32, pin_memory=True)
+        h_ids.copy_(ids, non_blocking=True)
+        h_ln.copy_(ln, non_blocking=True)
+        h_cf.copy_(conf, non_blocking=True)
+        return order, (h_ids, h_ln, h_cf)
 
     def _rec_gpu(self, items: np.ndarray, lens_np: np.ndarray, wb: int, slot: int, used_graphs: set):
         """Upload one crop table, run crop+CRNN+decode, start the D2H of the result.  Returns pinned host tensors."""

@@ -91,3 +91,41 @@ def test_crnn_gpu_matches_cpu_oracle():
         assert d.max().item() < 0.15, (n, d.max().item())
     ids, ln, conf = net.infer(x8.to("cuda"), lens.to("cuda"))
     assert ids.shape == (5, 40) and bool((ln.cpu() <= lens).all())
+
+
+def _ragged_case(device):
+    from distributed_llms_amd.ops.lstm import RaggedLayout
+
+    torch.manual_seed(0)
+    net = CRNN(hidden=64, widths=(16, 32, 32, 32, 64, 64)).eval()
+    _randomize_bn(net)
+    net = net.to(device).prepare()
+    xs = [torch.randn(3, 48, 64, 8) * 0.5, torch.randn(2, 48, 128, 8) * 0.5]
+    for x in xs:
+        x[..., 3:] = 0
+    xs = [x.to(torch.bfloat16).to(device) for x in xs]
+    lens = [torch.tensor([16, 9, 3], dtype=torch.int32), torch.tensor([32, 20], dtype=torch.int32)]
+    tcap = torch.tensor([16, 16, 16, 32, 32], dtype=torch.int32)
+    ln = torch.cat(lens)
+    row_off = (torch.cumsum(tcap.long(), 0) - tcap.long())
+    perm = torch.argsort(-ln.long(), stable=True).to(torch.int32)
+    lay = RaggedLayout(row_off.to(device), tcap.to(device), ln.to(device), perm.to(device), int(tcap.sum()), 32)
+    ids_r, len_r, conf_r = net.infer_ragged(xs, lay)
+    k = 0
+    for x, l in zip(xs, lens):
+        ids, n, conf = net.infer(x, l.to(device))
+        for j in range(x.shape[0]):
+            L = int(n[j])
+            assert int(len_r[k]) == L
+            assert torch.equal(ids_r[k, :L].cpu(), ids[j, :L].cpu())
+            assert abs(float(conf_r[k]) - float(conf[j])) < 2e-2
+            k += 1
+
+
+def test_crnn_ragged_equals_per_bucket_cpu():
+    _ragged_case("cpu")
+
+
+@pytest.mark.gpu
+def test_crnn_ragged_equals_per_bucket_gpu():
+    _ragged_case("cuda")
