@@ -355,7 +355,6 @@ extern "C" int dlamd_lstm_bidir(const void* xproj, const void* wfrag, const void
   // Shape selection: v1 (4 waves x 16 sequences) minimises latency for small batches; v2 (8 waves,
   // 32 sequences) halves W_hh traffic per sequence once there are enough sequences to fill CUs anyway.
   // DLAMD_LSTM_VARIANT (benchmarks only): 1 = v1, 2 = v2 with 16 sequences, 3 = v2 with 32 sequences.
-  const int var = variant_env();
   // Measured on MI355X (us per step, H=256, both directions): N=970: v1 10.5, v2x16 7.5, v2x32 10.0;
   // N=4000: v2x16 16.4, v2x32 13.1 -> 8-wave kernel everywhere, 32 sequences once CUs are oversubscribed.
   const int var = variant_env();

@@ -1,0 +1,249 @@
+"""API contract tests (one test per row of the reference's API.md) against the ASGI app with
+in-memory stores.  The CPU extractor runs the real pipeline: text PDFs through the native reader,
+scanned PDFs through tiny DBNet/CRNN models on the CPU oracle path."""
+import json
+import time
+
+import pytest
+from starlette.testclient import TestClient
+
+from distributed_llms_amd.api.app import create_app
+from distributed_llms_amd.api.multipart import encode_multipart
+from distributed_llms_amd.config import Settings
+from distributed_llms_amd.pdf import synth
+from distributed_llms_amd.store.results import MemoryResultStore
+from distributed_llms_amd.store.status import MemoryStatusStore
+
+LINES = ["The quick brown fox jumps over the lazy dog near the river bank today.",
+         "A second line of perfectly ordinary born-digital text follows the first one.", "",
+         "Another paragraph starts here and it is long enough to be counted as text."]
+
+
+class StubExtractor:
+    def __init__(self, result=None, delay=0.0):
+        self.result = result or {"status": "completed", "result": "stub text", "pages": 1}
+        self.delay = delay
+        self.calls = 0
+
+    def extract(self, pdf_bytes, document_id, document_hash=None):
+        self.calls += 1
+        if self.delay:
+            time.sleep(self.delay)
+        return dict(self.result)
+
+    def describe(self):
+        return {"backend": "stub"}
+
+    def close(self):
+        pass
+
+
+def _cpu_extractor():
+    from distributed_llms_amd.runtime.document import DocumentPipeline
+    from distributed_llms_amd.runtime.extractor import InlineExtractor
+    from distributed_llms_amd.runtime.workers import build_engine
+
+    eng = build_engine("cpu", {"model": "tiny", "cfg": dict(det_limit_side=160, rec_max_width=256,
+                                                             rec_width_quantum=64, max_batch_pages=2)})
+    return InlineExtractor(DocumentPipeline(eng, decode_threads=2))
+
+
+@pytest.fixture()
+def ctx(tmp_path):
+    settings = Settings(store="memory", output_dir=str(tmp_path / "out"), num_gpus=0, node_id="test-node")
+    status, results = MemoryStatusStore(), MemoryResultStore()
+    return settings, status, results
+
+
+def _post(client, pdf, doc_id, filename="doc.pdf", fields=None):
+    f = {"document_id": doc_id} if doc_id is not None else {}
+    f.update(fields or {})
+    body, ctype = encode_multipart(f, {"file": (filename, pdf, "application/pdf")})
+    return client.post("/extract", content=body, headers={"content-type": ctype})
+
+
+def _wait(client, doc_id, timeout=60.0):
+    t_end = time.time() + timeout
+    while time.time() < t_end:
+        r = client.get(f"/check-status/{doc_id}")
+        if r.status_code == 200 and r.json()["status"] != "processing":
+            return r.json()["status"]
+        time.sleep(0.02)
+    raise AssertionError("job did not finish")
+
+
+def test_extract_text_pdf_end_to_end(ctx):
+    settings, status, results = ctx
+    app = create_app(settings, status, results, _cpu_extractor())
+    pdf = synth.make_text_pdf([LINES, ["Page two has a single line of text that is long enough."]])
+    with TestClient(app) as c:
+        r = _post(c, pdf, "doc-1")
+        assert r.status_code == 200 and r.json() == {"status": "ok"}
+        assert _wait(c, "doc-1") == "completed"
+        r = c.get("/result/doc-1")
+        assert r.status_code == 200
+        body = r.json()
+        assert set(body) == {"document_id", "text", "status"} and body["status"] == "completed"
+        assert body["text"].startswith("The quick brown fox") and "Page two has a single line" in body["text"]
+        assert "\n\n" in body["text"]  # content-list items are joined with blank lines
+    # Mongo "checkpoint format": exactly six fields with the reference's types (2B-8)
+    doc = results.find("doc-1")
+    assert set(doc) == {"document_id", "combined_text", "status", "processed_at", "word_count", "character_count"}
+    assert doc["status"] == "completed" and doc["word_count"] == len(doc["combined_text"].split())
+    assert doc["character_count"] == len(doc["combined_text"])
+    # final Redis value holds the full text, the hash, no preview (2B-2); hash key points at the id
+    st = status.get("doc-1")
+    assert st["status"] == "completed" and st["result"] == doc["combined_text"] and "result_preview" not in st
+    assert status.document_for_hash(st["document_hash"]) == "doc-1"
+
+
+def test_extract_scanned_pdf_goes_through_ocr_branch(ctx):
+    settings, status, results = ctx
+    app = create_app(settings, status, results, _cpu_extractor())
+    pg, truth = synth.render_page(5, size=(248, 350), font_px=10, margin=16)
+    pdf = synth.make_scanned_pdf([pg], codec="flate", dpi=30)
+    with TestClient(app) as c:
+        assert _post(c, pdf, "scan-1").json() == {"status": "ok"}
+        assert _wait(c, "scan-1") in ("completed", "error")
+        r = c.get("/result/scan-1")
+        assert r.status_code == 200 and r.json()["status"] in ("completed", "failed")
+
+
+def test_rejects_non_pdf_and_empty_id_and_missing_fields(ctx):
+    settings, status, results = ctx
+    app = create_app(settings, status, results, StubExtractor())
+    with TestClient(app) as c:
+        r = _post(c, b"hello", "x", filename="notes.txt")
+        assert r.status_code == 400 and r.json() == {"detail": "Only PDF files are accepted"}
+        r = _post(c, b"%PDF-1.4", "", filename="a.PDF")
+        assert r.status_code == 400 and r.json() == {"detail": "document_id is required"}
+        r = _post(c, b"%PDF-1.4", None)
+        assert r.status_code == 422
+        r = c.post("/extract", content=b"garbage", headers={"content-type": "multipart/form-data; boundary=zz"})
+        assert r.status_code == 422
+        assert _post(c, b"%PDF-1.4", "up", filename="UPPER.PDF").status_code == 200  # suffix check is case-insensitive
+
+
+def test_duplicate_id_returns_raw_status_and_does_not_reprocess(ctx):
+    settings, status, results = ctx
+    ex = StubExtractor(delay=0.3)
+    app = create_app(settings, status, results, ex)
+    with TestClient(app) as c:
+        assert _post(c, b"%PDF-1.4 x", "dup").json() == {"status": "ok"}
+        again = _post(c, b"%PDF-1.4 x", "dup").json()
+        assert again["status"] in ("queued", "processing")      # raw lifecycle word leaks, as in the reference
+        assert _wait(c, "dup") == "completed"
+        assert _post(c, b"%PDF-1.4 x", "dup").json() == {"status": "completed"}
+        assert ex.calls == 1
+
+
+def test_failed_job_status_vocabulary_and_error_file(ctx, tmp_path):
+    settings, status, results = ctx
+    app = create_app(settings, status, results, StubExtractor({"status": "failed", "error": "boom"}))
+    with TestClient(app) as c:
+        _post(c, b"%PDF-1.4", "bad")
+        assert _wait(c, "bad") == "error"                        # public word
+        r = c.get("/result/bad")
+        assert r.status_code == 200 and r.json() == {
+            "document_id": "bad", "status": "failed", "message": "Document processing status: failed"}
+        assert _post(c, b"%PDF-1.4", "bad").json() == {"status": "failed"}   # cannot be retried until the TTL lapses
+    err = json.loads((tmp_path / "out" / "error_bad.json").read_text())
+    assert err["document_id"] == "bad" and err["status"] == "failed" and err["error"] == "boom"
+    assert results.find("bad") is None                           # failed documents never reach the result store
+
+
+def test_real_parse_failure_becomes_failed_status(ctx):
+    settings, status, results = ctx
+    app = create_app(settings, status, results, _cpu_extractor())
+    with TestClient(app) as c:
+        _post(c, b"this is not a pdf", "garbled")
+        assert _wait(c, "garbled") == "error"
+        assert "cannot parse PDF" in status.get("garbled")["error"]
+
+
+def test_unknown_ids(ctx):
+    settings, status, results = ctx
+    app = create_app(settings, status, results, StubExtractor())
+    with TestClient(app) as c:
+        r = c.get("/check-status/nope")
+        assert r.status_code == 404 and r.json() == {"status": "unknown", "error": "No record found for document ID: nope"}
+        r = c.get("/result/nope")
+        assert r.status_code == 404 and r.json() == {"error": "No record found for document ID: nope"}
+
+
+def test_result_survives_expired_status_key(ctx):
+    settings, status, results = ctx
+    app = create_app(settings, status, results, StubExtractor())
+    with TestClient(app) as c:
+        _post(c, b"%PDF-1.4", "old")
+        assert _wait(c, "old") == "completed"
+        status.delete("old")                                      # TTL lapsed; the Mongo row never expires
+        assert c.get("/check-status/old").status_code == 404
+        r = c.get("/result/old")
+        assert r.status_code == 200 and r.json() == {"document_id": "old", "text": "stub text", "status": "completed"}
+
+
+def test_health_states(ctx):
+    settings, status, results = ctx
+    app = create_app(settings, status, results, StubExtractor())
+    with TestClient(app) as c:
+        r = c.get("/health")
+        assert r.status_code == 200
+        b = r.json()
+        assert b["status"] == "healthy" and b["version"] == "1.0.0" and "timestamp" in b
+        assert b["dependencies"] == {"redis": "healthy", "mongodb": "healthy"}
+        results.healthy = False
+        r = c.get("/health")
+        assert r.status_code == 503 and r.json()["status"] == "unhealthy" and r.json()["dependencies"]["mongodb"] == "unhealthy"
+        results.healthy = True
+        status.healthy = False
+        r = c.get("/health")
+        assert r.status_code == 503 and r.json()["dependencies"]["redis"] == "unhealthy"
+        # /result with the status store down -> 500 with the reference's error body
+        r = c.get("/result/x")
+        assert r.status_code == 500 and r.json()["error"].startswith("Error retrieving result:")
+        status.healthy = True
+        results.ping = lambda: {"ok": 0}
+        r = c.get("/health")
+        assert r.status_code == 200 and r.json()["status"] == "degraded"
+
+
+def test_write_order_result_row_exists_before_completed(ctx):
+    """2B-2: the result store is written before any status says 'completed'."""
+    settings, status, results = ctx
+    seen = []
+    orig = status.update
+
+    def spy(document_id, data):
+        seen.append((data["status"], results.find(document_id) is not None, "result_preview" in data, "result" in data))
+        return orig(document_id, data)
+
+    status.update = spy
+    app = create_app(settings, status, results, StubExtractor())
+    with TestClient(app) as c:
+        _post(c, b"%PDF-1.4", "ord")
+        assert _wait(c, "ord") == "completed"
+    assert [s[0] for s in seen] == ["processing", "completed", "completed"]
+    assert seen[1] == ("completed", True, True, False) and seen[2] == ("completed", True, False, True)
+
+
+def test_metrics_and_cors(ctx):
+    settings, status, results = ctx
+    app = create_app(settings, status, results, StubExtractor())
+    with TestClient(app) as c:
+        _post(c, b"%PDF-1.4", "m1")
+        _wait(c, "m1")
+        text = c.get("/metrics").text
+        assert "ocr_documents_total" in text and "ocr_stage_seconds_bucket" in text
+        r = c.options("/extract", headers={"origin": "http://example.com", "access-control-request-method": "POST"})
+        assert r.headers.get("access-control-allow-origin") in ("*", "http://example.com")
+
+
+def test_orphan_sweep_on_startup(ctx):
+    settings, status, results = ctx
+    status.update("stuck", {"status": "processing", "owner": "test-node"})
+    status.update("other", {"status": "processing", "owner": "someone-else"})
+    app = create_app(settings, status, results, StubExtractor())
+    with TestClient(app) as c:
+        assert c.get("/check-status/stuck").json() == {"status": "error"}
+        assert c.get("/check-status/other").json() == {"status": "processing"}
