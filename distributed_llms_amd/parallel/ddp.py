@@ -31,9 +31,9 @@ class Bucket:
     flat_param: torch.Tensor
     flat_grad: torch.Tensor
     offsets: List[int]
+    used: int = 0          # elements actually occupied by parameters (the rest is world-size padding)
     pending: int = 0
     handle: Optional[object] = None
-    ready_count: int = 0
 
 
 def _align(n: int, a: int) -> int:
@@ -67,6 +67,7 @@ class FlatBuckets:
             for p in g:
                 offs.append(total)
                 total += _align(p.numel(), 4)
+            used = total
             total = _align(total, max(pad_to, 4))
             fp = torch.zeros(total, dtype=dtype, device=device)
             fg = torch.zeros(total, dtype=dtype, device=device)
@@ -74,13 +75,16 @@ class FlatBuckets:
                 fp[o : o + p.numel()].copy_(p.data.reshape(-1))
                 p.data = fp[o : o + p.numel()].view_as(p.data)
                 p.grad = fg[o : o + p.numel()].view_as(p.data)
-            b = Bucket(g, fp, fg, offs)
-            for p in g:
-                self._bucket_of[p] = len(self.buckets)
+            b = Bucket(g, fp, fg, offs, used)
+            for p, o in zip(g, offs):
+                self._bucket_of[id(p)] = (len(self.buckets), o)   # keyed by identity: tensors compare elementwise
             self.buckets.append(b)
 
     def bucket_index(self, p: torch.nn.Parameter) -> int:
-        return self._bucket_of[p]
+        return self._bucket_of[id(p)][0]
+
+    def offset_of(self, p: torch.nn.Parameter) -> int:
+        return self._bucket_of[id(p)][1]
 
     def zero_grad(self) -> None:
         for b in self.buckets:
@@ -129,7 +133,7 @@ class BucketedDDP:
 
     def _on_grad(self, p: torch.nn.Parameter) -> None:
         b = self.flat.buckets[self.flat.bucket_index(p)]
-        off = b.offsets[b.params.index(p)]
+        off = self.flat.offset_of(p)
         want = b.flat_grad.data_ptr() + off * b.flat_grad.element_size()
         if p.grad is not None and p.grad.data_ptr() != want:
             # autograd produced a fresh tensor instead of accumulating into our view: fold it back

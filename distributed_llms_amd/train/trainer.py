@@ -65,7 +65,9 @@ class CTCTrainer:
         self.model.train()
         self.ddp = BucketedDDP(self.model, cfg.bucket_mb, cfg.dp_mode)
         flats = [(b.flat_param, b.flat_grad) for b in self.ddp.flat.buckets]
-        shards = None
+        # unsharded: update exactly the occupied prefix (the padding depends on the world size; keeping it out
+        # of the norm reduction makes DP=N on identical shards bitwise equal to DP=1)
+        shards = [(0, b.used) for b in self.ddp.flat.buckets]
         if cfg.dp_mode == "rs_ag" and self.ddp.world > 1:
             shards = [self.ddp.shard_range(b) for b in self.ddp.flat.buckets]
         self.opt = FlatAdamW(flats, lr=cfg.lr, weight_decay=cfg.weight_decay, max_grad_norm=cfg.max_grad_norm,

@@ -1,0 +1,192 @@
+"""Native PDF reader: structure variants, text operators, encodings, images, classifier, JPEG scan."""
+import io
+import zlib
+
+import numpy as np
+import pytest
+
+from distributed_llms_amd.pdf import reader, synth
+
+TEXT = [["Hello world, this is page one of a born-digital document with plenty of text.",
+         "Second line (with parens) and a \\ backslash to exercise string escapes.", "",
+         "Another paragraph begins here, after a vertical gap, and keeps going for a while."],
+        ["Page two is short but still text."]]
+
+
+@pytest.mark.parametrize("xref_stream", [False, True])
+@pytest.mark.parametrize("tj", [False, True])
+@pytest.mark.parametrize("compress", [False, True])
+def test_text_extraction_variants(xref_stream, tj, compress):
+    pdf = synth.make_text_pdf(TEXT, xref_stream=xref_stream, use_tj_arrays=tj, compress=compress)
+    with reader.PdfDocument(pdf) as d:
+        assert d.page_count == 2
+        t0 = d.page_text(0)
+        assert t0.split("\n\n") == ["\n".join(TEXT[0][:2]), TEXT[0][3]]      # lines, then a paragraph break
+        assert d.page_text(1) == TEXT[1][0]
+        c = d.classify()
+        assert c.is_text and c.pages_image_dominant == 0 and c.garbled_ratio == 0
+        pi = d.page_info(0)
+        assert abs(pi.width_pt - 595.28) < 0.01 and pi.n_images == 0 and pi.chars_visible > 150
+
+
+def _raw_pdf(objs, root=1):
+    out = io.BytesIO()
+    out.write(b"%PDF-1.4\n")
+    offs = []
+    for i, b in enumerate(objs, 1):
+        offs.append(out.tell())
+        out.write(b"%d 0 obj\n" % i + b + b"\nendobj\n")
+    x = out.tell()
+    out.write(b"xref\n0 %d\n0000000000 65535 f \n" % (len(objs) + 1))
+    for o in offs:
+        out.write(b"%010d 00000 n \n" % o)
+    out.write(b"trailer\n<< /Size %d /Root %d 0 R >>\nstartxref\n%d\n%%%%EOF\n" % (len(objs) + 1, root, x))
+    return out.getvalue()
+
+
+def _stream(d, data):
+    return b"<< " + d + b" /Length %d >>\nstream\n" % len(data) + data + b"\nendstream"
+
+
+def test_encodings_tounicode_hex_strings_and_positioning():
+    cmap = (b"/CIDInit /ProcSet findresource begin 12 dict begin begincmap\n1 begincodespacerange <0000> <FFFF> endcodespacerange\n"
+            b"2 beginbfchar <0003> <0048> <0004> <00E9> endbfchar\n1 beginbfrange <0010> <0012> <006A> endbfrange\nendcmap end end")
+    content = (b"BT /F1 12 Tf 72 700 Td (caf\\351 \\223quoted\\224) Tj ET\n"          # WinAnsi octal escapes
+               b"BT /F2 12 Tf 72 680 Td <00030004001000110012> Tj ET\n"                 # Identity-H + ToUnicode
+               b"BT /F3 12 Tf 72 660 Td (ab) Tj ET\n"                                   # Differences -> glyph names
+               b"BT /F1 12 Tf 1 0 0 1 72 640 Tm (left) Tj 200 0 Td (right) Tj ET\n"     # same line, big gap -> space
+               b"q 2 0 0 2 0 0 cm BT /F1 6 Tf 36 310 Td (scaled) Tj ET Q\n"
+               b"BT /F1 12 Tf 3 Tr 72 600 Td (hidden layer) Tj ET")
+    objs = [
+        b"<< /Type /Catalog /Pages 2 0 R >>",
+        b"<< /Type /Pages /Count 1 /Kids [3 0 R] >>",
+        b"<< /Type /Page /Parent 2 0 R /MediaBox [0 0 612 792] /Contents 4 0 R /Resources << /Font << /F1 5 0 R /F2 6 0 R /F3 9 0 R >> >> >>",
+        _stream(b"", content),
+        b"<< /Type /Font /Subtype /Type1 /BaseFont /Helvetica /Encoding /WinAnsiEncoding >>",
+        b"<< /Type /Font /Subtype /Type0 /BaseFont /X /Encoding /Identity-H /DescendantFonts [7 0 R] /ToUnicode 8 0 R >>",
+        b"<< /Type /Font /Subtype /CIDFontType2 /BaseFont /X /DW 600 >>",
+        _stream(b"", cmap),
+        b"<< /Type /Font /Subtype /Type1 /BaseFont /Foo /Encoding << /BaseEncoding /WinAnsiEncoding /Differences [97 /Euro /fi] >> >>",
+    ]
+    with reader.PdfDocument(_raw_pdf(objs)) as d:
+        lines = d.page_text(0).replace("\n\n", "\n").split("\n")
+        assert lines[0] == "café “quoted”"
+        assert lines[1] == "Héjkl"
+        assert lines[2] == "€ﬁ"
+        assert lines[3] == "left right"
+        assert lines[4] == "scaled"
+        assert "hidden layer" not in d.page_text(0) and "hidden layer" in d.page_text(0, include_invisible=True)
+        pi = d.page_info(0)
+        assert pi.chars_invisible == len("hiddenlayer") and pi.unmapped == 0
+
+
+def test_object_streams_incremental_update_and_rebuild():
+    # PDF 1.5 object stream holding the catalog and page tree
+    inner = [b"<< /Type /Catalog /Pages 2 0 R >>", b"<< /Type /Pages /Count 1 /Kids [3 0 R] >>"]
+    hdr, body = b"", b""
+    for k, o in enumerate(inner):
+        hdr += b"%d %d " % (k + 1, len(body))
+        body += o + b"\n"
+    objstm_data = zlib.compress(hdr + body)
+    objstm = _stream(b"/Type /ObjStm /N 2 /First %d /Filter /FlateDecode" % len(hdr), objstm_data)
+    page = b"<< /Type /Page /Parent 2 0 R /MediaBox [0 0 200 200] /Contents 4 0 R /Resources << /Font << /F1 5 0 R >> >> >>"
+    content = _stream(b"", b"BT /F1 10 Tf 10 100 Td (from object stream) Tj ET")
+    font = b"<< /Type /Font /Subtype /Type1 /BaseFont /Courier >>"
+    out = io.BytesIO()
+    out.write(b"%PDF-1.5\n")
+    offs = {}
+    for num, b in ((3, page), (4, content), (5, font), (6, objstm)):
+        offs[num] = out.tell()
+        out.write(b"%d 0 obj\n" % num + b + b"\nendobj\n")
+    xpos = out.tell()
+    rows = bytes([0, 0, 0, 0, 0]) + bytes([2, 0, 0, 6, 0]) + bytes([2, 0, 0, 6, 1])
+    for num in (3, 4, 5, 6):
+        rows += bytes([1]) + offs[num].to_bytes(3, "big") + bytes([0])
+    rows += bytes([1]) + xpos.to_bytes(3, "big") + bytes([0])
+    out.write(b"7 0 obj\n" + _stream(b"/Type /XRef /Size 8 /W [1 3 1] /Root 1 0 R", rows) + b"\nendobj\n")
+    out.write(b"startxref\n%d\n%%%%EOF\n" % xpos)
+    pdf = out.getvalue()
+    with reader.PdfDocument(pdf) as d:
+        assert d.page_count == 1 and d.page_text(0) == "from object stream" and not d.was_rebuilt
+    # incremental update: a newer revision of the content stream appended with /Prev
+    base = synth.make_text_pdf([["old text that will be replaced by an incremental update"]], compress=False)
+    sx = int(base[base.rindex(b"startxref") + 9:].split()[0])
+    new_obj = _stream(b"", b"BT /F1 11 Tf 72 770 Td (new text wins) Tj ET")
+    upd = io.BytesIO()
+    upd.write(base)
+    pos = upd.tell()
+    upd.write(b"4 0 obj\n" + new_obj + b"\nendobj\n")
+    xp = upd.tell()
+    upd.write(b"xref\n4 1\n%010d 00000 n \ntrailer\n<< /Size 6 /Root 1 0 R /Prev %d >>\nstartxref\n%d\n%%%%EOF\n" % (pos, sx, xp))
+    with reader.PdfDocument(upd.getvalue()) as d:
+        assert d.page_text(0) == "new text wins"
+    # damaged xref offsets -> full rebuild by scanning for objects
+    broken = base.replace(b"startxref\n%d" % sx, b"startxref\n%d" % (sx + 7))
+    with reader.PdfDocument(broken) as d:
+        assert d.was_rebuilt and "old text" in d.page_text(0)
+    with pytest.raises(reader.PdfError):
+        reader.PdfDocument(b"%PDF-1.4\nnothing useful")
+    with pytest.raises(reader.PdfError):
+        reader.PdfDocument(b"plain text")
+
+
+def test_scanned_pages_images_and_classifier():
+    pg, _ = synth.render_page(2, size=(320, 452), font_px=11, margin=24)
+    rgb = np.stack([pg, pg // 2, 255 - pg], axis=-1)
+    for codec in ("flate", "jpeg"):
+        pdf = synth.make_scanned_pdf([pg, rgb], codec=codec, dpi=40, restart_blocks=10)
+        with reader.PdfDocument(pdf) as d:
+            c = d.classify()
+            assert not c.is_text and c.pages_image_dominant == 2 and c.avg_coverage > 0.99
+            im0, im1 = d.main_image(0), d.main_image(1)
+            assert (im0.width, im0.height, im0.out_channels) == (320, 452, 1) and im1.out_channels == 3
+            if codec == "flate":
+                assert im0.codec == reader.CODEC_RAW
+                assert np.array_equal(d.decode_image(im0), pg) and np.array_equal(d.decode_image(im1), rgb)
+                buf = np.zeros(320 * 452 + 64, dtype=np.uint8)
+                assert np.array_equal(d.decode_image(im0, buf), pg)            # decode into caller memory
+            else:
+                assert im0.codec == reader.CODEC_JPEG and im0.stream_off > 0
+                sc = reader.scan_jpeg(d.jpeg_bytes(im0))
+                assert (sc.info.width, sc.info.height, sc.info.ncomp) == (320, 452, 1)
+                assert sc.info.restart_interval == 10 and sc.gpu_decodable
+                assert sc.info.n_segments == -(-(sc.info.mcus_x * sc.info.mcus_y) // 10)
+                assert sc.seg_offsets[0] == sc.info.scan_off and np.all(np.diff(sc.seg_offsets.astype(np.int64)) > 2)
+
+
+def test_image_formats_bilevel_indexed_predictor():
+    W, H = 37, 9
+    rng = np.random.default_rng(0)
+    bits = rng.integers(0, 2, size=(H, W), dtype=np.uint8)
+    packed = np.packbits(bits, axis=1).tobytes()
+    idx = rng.integers(0, 4, size=(H, W), dtype=np.uint8)
+    palette = bytes([0, 0, 0, 255, 0, 0, 0, 255, 0, 255, 255, 255])
+    gray = rng.integers(0, 255, size=(H, W), dtype=np.uint8)
+    # PNG "Sub" predictor rows
+    pred = b"".join(b"\x01" + np.diff(np.concatenate([[0], r.astype(np.int16)])).astype(np.uint8).tobytes() for r in gray)
+
+    def page_with(img_dict, data):
+        objs = [b"<< /Type /Catalog /Pages 2 0 R >>", b"<< /Type /Pages /Count 1 /Kids [3 0 R] >>",
+                b"<< /Type /Page /Parent 2 0 R /MediaBox [0 0 100 100] /Contents 4 0 R /Resources << /XObject << /I 5 0 R >> >> >>",
+                _stream(b"", b"q 100 0 0 100 0 0 cm /I Do Q"),
+                _stream(b"/Type /XObject /Subtype /Image /Width %d /Height %d " % (W, H) + img_dict, data)]
+        return _raw_pdf(objs)
+
+    with reader.PdfDocument(page_with(b"/ColorSpace /DeviceGray /BitsPerComponent 1", packed)) as d:
+        assert np.array_equal(d.decode_image(d.main_image(0)), bits * 255)
+    with reader.PdfDocument(page_with(b"/ImageMask true /BitsPerComponent 1", packed)) as d:
+        assert np.array_equal(d.decode_image(d.main_image(0)), (1 - bits) * 255)   # stencil: 0 paints ink
+    with reader.PdfDocument(page_with(b"/ColorSpace [/Indexed /DeviceRGB 3 <%s>] /BitsPerComponent 8" % palette.hex().encode(),
+                                      idx.tobytes())) as d:
+        out = d.decode_image(d.main_image(0))
+        assert out.shape == (H, W, 3) and np.array_equal(out, np.frombuffer(palette, np.uint8).reshape(4, 3)[idx])
+    dp = b"/ColorSpace /DeviceGray /BitsPerComponent 8 /Filter /FlateDecode /DecodeParms << /Predictor 11 /Columns %d >>" % W
+    with reader.PdfDocument(page_with(dp, zlib.compress(pred))) as d:
+        assert np.array_equal(d.decode_image(d.main_image(0)), gray)
+    with reader.PdfDocument(page_with(b"/ColorSpace /DeviceGray /BitsPerComponent 1 /Filter /JBIG2Decode", b"xx")) as d:
+        assert d.main_image(0).codec == reader.CODEC_UNSUPPORTED
+
+
+def test_short_born_digital_document_is_text_not_ocr():
+    with reader.PdfDocument(synth.make_text_pdf([["Tiny note."]])) as d:
+        assert d.classify().is_text
