@@ -1,0 +1,331 @@
+"""ViT-encoder + Transformer-decoder line recognizer, TrOCR-base-sized (BASELINE config 4).
+
+Sizes (defaults): 384 x 384 crop -> 24 x 24 patches of 16 x 16 + CLS = 577 tokens, encoder 12 x
+(d = 768, 12 heads, MLP 3072); decoder 12 x (d = 1024, 16 heads, FFN 4096, cross-attention over the
+577 encoder tokens), vocabulary 50 265, ~330 M parameters.  Both stacks are pre-LN; weights are
+random-init (no checkpoint is reachable offline), so this matches TrOCR-base in *shape and cost*,
+not in its exact normalisation placement.
+
+MI355X inference path (``encode`` / ``generate``):
+* patch embedding = the MFMA implicit-GEMM conv (16 x 16 stride 16, K = 2048);
+* every linear = the same kernel's 1x1 path with bias / GELU / residual fused in the epilogue;
+  Q, K, V are one fused [3d, d] GEMM, cross-attention K/V for all 577 memory tokens one [2d, d_enc] GEMM
+  per layer, computed once per batch;
+* encoder attention = flash-style MFMA kernel streaming K/V through LDS in 64-key blocks;
+* one greedy decode step (embed -> 12 layers -> LM-head GEMM -> argmax -> step counter) has fully static
+  launch parameters: the step index lives in device memory and the decode-attention kernel appends to the
+  KV cache itself, so the whole step (~140 launches) is captured ONCE per batch bucket in a hipGraph and
+  replayed per generated token (N17).  Decode is GEMV-shaped at small batch, so crops are batched (>= 256).
+
+``forward_reference`` is the plain PyTorch fp32 implementation over the same parameters (test oracle).
+In the reference service this role is played by magic-pdf's UniMERNet / OCR recognizers on CPU
+(services/ocr_service/download_models_hf.py:40-41).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..ops import ctc as ctc_ops
+from ..ops import transformer as T
+from ..ops.conv import conv2d_nhwc, linear_bf16
+
+
+@dataclass
+class TrOCRConfig:
+    image_size: int = 384
+    patch: int = 16
+    enc_dim: int = 768
+    enc_layers: int = 12
+    enc_heads: int = 12
+    enc_mlp: int = 3072
+    dec_dim: int = 1024
+    dec_layers: int = 12
+    dec_heads: int = 16
+    dec_ffn: int = 4096
+    vocab: int = 50265
+    max_len: int = 128
+    bos: int = 0
+    pad: int = 1
+    eos: int = 2
+
+    @property
+    def tokens(self) -> int:
+        return (self.image_size // self.patch) ** 2 + 1
+
+    @property
+    def vocab_padded(self) -> int:
+        return (self.vocab + 15) // 16 * 16
+
+
+class _EncLayer(nn.Module):
+    def __init__(self, d: int, mlp: int):
+        super().__init__()
+        self.ln1, self.ln2 = nn.LayerNorm(d), nn.LayerNorm(d)
+        self.qkv, self.proj = nn.Linear(d, 3 * d), nn.Linear(d, d)
+        self.fc1, self.fc2 = nn.Linear(d, mlp), nn.Linear(mlp, d)
+
+
+class _DecLayer(nn.Module):
+    def __init__(self, d: int, d_enc: int, ffn: int):
+        super().__init__()
+        self.ln1, self.ln2, self.ln3 = nn.LayerNorm(d), nn.LayerNorm(d), nn.LayerNorm(d)
+        self.qkv, self.proj = nn.Linear(d, 3 * d), nn.Linear(d, d)
+        self.xq, self.xkv, self.xproj = nn.Linear(d, d), nn.Linear(d_enc, 2 * d), nn.Linear(d, d)
+        self.fc1, self.fc2 = nn.Linear(d, ffn), nn.Linear(ffn, d)
+
+
+def _pk(lin: nn.Linear):
+    return lin.weight.detach().to(torch.bfloat16).contiguous(), lin.bias.detach().float().contiguous()
+
+
+def _ln(ln: nn.LayerNorm):
+    return ln.weight.detach().float().contiguous(), ln.bias.detach().float().contiguous()
+
+
+class TrOCR(nn.Module):
+    def __init__(self, cfg: Optional[TrOCRConfig] = None):
+        super().__init__()
+        self.cfg = cfg = cfg or TrOCRConfig()
+        assert cfg.enc_dim == 64 * cfg.enc_heads and cfg.dec_dim == 64 * cfg.dec_heads, "head dim is 64"
+        self.patch_embed = nn.Conv2d(3, cfg.enc_dim, cfg.patch, cfg.patch)
+        self.cls = nn.Parameter(torch.zeros(1, 1, cfg.enc_dim))
+        self.enc_pos = nn.Parameter(torch.randn(1, cfg.tokens, cfg.enc_dim) * 0.02)
+        self.enc = nn.ModuleList([_EncLayer(cfg.enc_dim, cfg.enc_mlp) for _ in range(cfg.enc_layers)])
+        self.enc_ln = nn.LayerNorm(cfg.enc_dim)
+        self.tok = nn.Embedding(cfg.vocab, cfg.dec_dim)
+        self.pos = nn.Embedding(cfg.max_len, cfg.dec_dim)
+        self.dec = nn.ModuleList([_DecLayer(cfg.dec_dim, cfg.enc_dim, cfg.dec_ffn) for _ in range(cfg.dec_layers)])
+        self.dec_ln = nn.LayerNorm(cfg.dec_dim)
+        self.lm_head = nn.Linear(cfg.dec_dim, cfg.vocab, bias=False)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, std=0.02)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Embedding):
+                nn.init.normal_(m.weight, std=0.02)
+        self._pk: Optional[Dict] = None
+        self._graphs: Dict[int, "_DecodeGraph"] = {}
+
+    def _apply(self, fn, *a, **k):
+        self._pk = None
+        self._graphs = {}
+        return super()._apply(fn, *a, **k)
+
+    def num_params(self) -> int:
+        return sum(p.numel() for p in self.parameters())
+
+    # ------------------------------------------------------------------ PyTorch fp32 reference
+    def encode_reference(self, x: torch.Tensor) -> torch.Tensor:
+        """x: [B, 3, S, S] normalised -> memory [B, tokens, enc_dim]."""
+        cfg = self.cfg
+        h = self.patch_embed(x).flatten(2).transpose(1, 2)
+        h = torch.cat([self.cls.expand(h.shape[0], -1, -1), h], 1) + self.enc_pos
+        for l in self.enc:
+            y = l.ln1(h)
+            q, k, v = l.qkv(y).chunk(3, -1)
+            h = h + l.proj(T.attention_reference(q, k, v, cfg.enc_heads, 0.125))
+            h = h + l.fc2(F.gelu(l.fc1(l.ln2(h))))
+        return self.enc_ln(h)
+
+    def decode_logits_reference(self, memory: torch.Tensor, tokens: torch.Tensor) -> torch.Tensor:
+        """Teacher-forced decoder: tokens [B, L] -> logits [B, L, vocab]."""
+        cfg = self.cfg
+        L = tokens.shape[1]
+        x = self.tok(tokens) + self.pos(torch.arange(L, device=tokens.device))[None]
+        for l in self.dec:
+            q, k, v = l.qkv(l.ln1(x)).chunk(3, -1)
+            x = x + l.proj(T.attention_reference(q, k, v, cfg.dec_heads, 0.125, causal=True))
+            xk, xv = l.xkv(memory).chunk(2, -1)
+            x = x + l.xproj(T.attention_reference(l.xq(l.ln2(x)), xk, xv, cfg.dec_heads, 0.125))
+            x = x + l.fc2(F.gelu(l.fc1(l.ln3(x))))
+        return self.lm_head(self.dec_ln(x))
+
+    @torch.no_grad()
+    def generate_reference(self, x: torch.Tensor, max_len: int) -> torch.Tensor:
+        mem = self.encode_reference(x)
+        toks = torch.full((x.shape[0], 1), self.cfg.bos, dtype=torch.long, device=x.device)
+        for _ in range(max_len):
+            nxt = self.decode_logits_reference(mem, toks)[:, -1].argmax(-1, keepdim=True)
+            toks = torch.cat([toks, nxt], 1)
+        return toks[:, 1:]
+
+    # ------------------------------------------------------------------ MI355X inference path
+    def prepare(self) -> "TrOCR":
+        self.eval()
+        cfg = self.cfg
+        dev = self.lm_head.weight.device
+        pk: Dict = {}
+        w = self.patch_embed.weight.detach().float()                       # [D, 3, p, p]
+        wp = torch.zeros(cfg.enc_dim, cfg.patch, cfg.patch, 8, device=dev)
+        wp[..., :3] = w.permute(0, 2, 3, 1)
+        pk["patch"] = (wp.to(torch.bfloat16).contiguous(), self.patch_embed.bias.detach().float().contiguous())
+        pk["cls_pos"] = (self.cls.detach() + self.enc_pos.detach()[:, :1]).to(torch.bfloat16).contiguous()
+        pk["pos"] = self.enc_pos.detach()[:, 1:].to(torch.bfloat16).contiguous()
+        pk["enc"] = [dict(ln1=_ln(l.ln1), ln2=_ln(l.ln2), qkv=_pk(l.qkv), proj=_pk(l.proj), fc1=_pk(l.fc1),
+                          fc2=_pk(l.fc2)) for l in self.enc]
+        pk["enc_ln"] = _ln(self.enc_ln)
+        pk["dec"] = [dict(ln1=_ln(l.ln1), ln2=_ln(l.ln2), ln3=_ln(l.ln3), qkv=_pk(l.qkv), proj=_pk(l.proj),
+                          xq=_pk(l.xq), xkv=_pk(l.xkv), xproj=_pk(l.xproj), fc1=_pk(l.fc1), fc2=_pk(l.fc2))
+                     for l in self.dec]
+        pk["dec_ln"] = _ln(self.dec_ln)
+        pk["tok"] = self.tok.weight.detach().to(torch.bfloat16).contiguous()
+        pk["dpos"] = self.pos.weight.detach().to(torch.bfloat16).contiguous()
+        lw = torch.zeros(cfg.vocab_padded, cfg.dec_dim, device=dev)
+        lw[: cfg.vocab] = self.lm_head.weight.detach().float()
+        lb = torch.full((cfg.vocab_padded,), -1e4, device=dev)
+        lb[: cfg.vocab] = 0.0
+        pk["lm"] = (lw.to(torch.bfloat16).contiguous(), lb.contiguous())
+        self._pk = pk
+        self._graphs = {}
+        return self
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor) -> torch.Tensor:
+        """x: [B, S, S, 8] NHWC bf16 (3 real channels) -> memory [B, tokens, enc_dim] bf16."""
+        if self._pk is None:
+            self.prepare()
+        cfg, pk = self.cfg, self._pk
+        B = x.shape[0]
+        n = cfg.tokens
+        h = torch.empty((B, n, cfg.enc_dim), dtype=torch.bfloat16, device=x.device)
+        pe = conv2d_nhwc(x, pk["patch"][0], pk["patch"][1], stride=cfg.patch)      # [B, g, g, D]
+        h[:, 1:] = pe.reshape(B, n - 1, cfg.enc_dim) + pk["pos"]
+        h[:, :1] = pk["cls_pos"]
+        for l in pk["enc"]:
+            y = T.layernorm(h, *l["ln1"])
+            qkv = linear_bf16(y, *l["qkv"])
+            d = cfg.enc_dim
+            a = T.attention(qkv[..., :d], qkv[..., d : 2 * d], qkv[..., 2 * d :], cfg.enc_heads)
+            h = linear_bf16(a, *l["proj"], res=h)
+            y = T.layernorm(h, *l["ln2"])
+            y = linear_bf16(y, *l["fc1"], act="gelu")
+            h = linear_bf16(y, *l["fc2"], res=h)
+        return T.layernorm(h, *pk["enc_ln"])
+
+    def _decode_step(self, st: "_DecodeState") -> None:
+        """One greedy step on the static state (tokens, t, caches) - the body that gets graph-captured."""
+        cfg, pk = self.cfg, self._pk
+        d = cfg.dec_dim
+        x = T.embed_rows(st.tokens, pk["tok"], pk["dpos"], st.t)
+        for li, l in enumerate(pk["dec"]):
+            y = T.layernorm(x, *l["ln1"])
+            qkv = linear_bf16(y, *l["qkv"])
+            a = T.attention_decode(qkv[:, :d], st.k_self[li], st.v_self[li], cfg.dec_heads,
+                                   k_new=qkv[:, d : 2 * d], v_new=qkv[:, 2 * d :], t=st.t)
+            x = linear_bf16(a, *l["proj"], res=x)
+            y = T.layernorm(x, *l["ln2"])
+            q = linear_bf16(y, *l["xq"])
+            a = T.attention_decode(q, st.k_cross[li], st.v_cross[li], cfg.dec_heads, klen=cfg.tokens)
+            x = linear_bf16(a, *l["xproj"], res=x)
+            y = T.layernorm(x, *l["ln3"])
+            y = linear_bf16(y, *l["fc1"], act="gelu")
+            x = linear_bf16(y, *l["fc2"], res=x)
+        x = T.layernorm(x, *pk["dec_ln"])
+        logits = linear_bf16(x, *pk["lm"])
+        idx, prob = ctc_ops.row_argmax(logits)
+        st.tokens.copy_(idx)
+        st.probs.copy_(prob)
+        st.t.add_(1)
+
+    @torch.no_grad()
+    def generate(self, x: torch.Tensor, max_len: Optional[int] = None, use_graph: bool = True
+                 ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """x: [B, S, S, 8] bf16 -> (tokens [B, max_len] int32, mean token probability [B])."""
+        if self._pk is None:
+            self.prepare()
+        cfg, pk = self.cfg, self._pk
+        max_len = min(max_len or cfg.max_len, cfg.max_len)
+        B = x.shape[0]
+        mem = self.encode(x)
+        on_gpu = x.is_cuda
+        Bb = B if not on_gpu else max(16, 1 << (B - 1).bit_length())
+        g = self._graphs.get(Bb)
+        if g is None:
+            g = _DecodeGraph(self, Bb, capture=on_gpu and use_graph)
+            self._graphs[Bb] = g
+        st = g.state
+        # cross-attention K/V of every layer, once per batch
+        for li, l in enumerate(pk["dec"]):
+            kv = linear_bf16(mem, *l["xkv"])
+            st.k_cross[li][:B].copy_(kv[..., : cfg.dec_dim])
+            st.v_cross[li][:B].copy_(kv[..., cfg.dec_dim :])
+        st.tokens.fill_(cfg.bos)
+        st.t.zero_()
+        out = torch.empty((max_len, Bb), dtype=torch.int32, device=x.device)
+        psum = torch.zeros((Bb,), dtype=torch.float32, device=x.device)
+        for s in range(max_len):
+            g.step()
+            out[s].copy_(st.tokens)
+            psum += st.probs
+        return out[:, :B].t().contiguous(), (psum[:B] / max_len)
+
+    def tokens_to_text(self, tokens: torch.Tensor) -> List[str]:
+        """Byte-level vocabulary: ids 0..3 are specials (bos, pad, eos, unk), 4..259 are the raw bytes."""
+        out = []
+        for row in tokens.cpu().tolist():
+            bs = bytearray()
+            for t in row:
+                if t == self.cfg.eos:
+                    break
+                if 4 <= t < 260:
+                    bs.append(t - 4)
+            out.append(bs.decode("utf-8", "replace"))
+        return out
+
+    def flops_per_crop(self, decode_tokens: int) -> float:
+        cfg = self.cfg
+        n, d, m = cfg.tokens, cfg.enc_dim, cfg.enc_mlp
+        enc = cfg.enc_layers * (2.0 * n * d * (4 * d + 2 * m) + 4.0 * n * n * d) + 2.0 * (n - 1) * 3 * cfg.patch ** 2 * d
+        dd, f = cfg.dec_dim, cfg.dec_ffn
+        cross_kv = cfg.dec_layers * 2.0 * n * d * 2 * dd
+        per_tok = cfg.dec_layers * (2.0 * dd * (4 * dd + 2 * dd + 2 * f) + 4.0 * n * dd) + 2.0 * dd * cfg.vocab
+        return enc + cross_kv + decode_tokens * per_tok
+
+
+class _DecodeState:
+    def __init__(self, model: TrOCR, Bb: int, device):
+        cfg = model.cfg
+        z = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=device)
+        self.tokens = torch.zeros((Bb,), dtype=torch.int32, device=device)
+        self.probs = torch.zeros((Bb,), dtype=torch.float32, device=device)
+        self.t = torch.zeros((1,), dtype=torch.int32, device=device)
+        self.k_self = [z(Bb, cfg.max_len, cfg.dec_dim) for _ in range(cfg.dec_layers)]
+        self.v_self = [z(Bb, cfg.max_len, cfg.dec_dim) for _ in range(cfg.dec_layers)]
+        self.k_cross = [z(Bb, cfg.tokens, cfg.dec_dim) for _ in range(cfg.dec_layers)]
+        self.v_cross = [z(Bb, cfg.tokens, cfg.dec_dim) for _ in range(cfg.dec_layers)]
+
+
+class _DecodeGraph:
+    """Static decode state + (on GPU) the captured hipGraph of one greedy step for a batch bucket."""
+
+    def __init__(self, model: TrOCR, Bb: int, capture: bool):
+        self.model = model
+        dev = model.lm_head.weight.device
+        self.state = _DecodeState(model, Bb, dev)
+        self.graph = None
+        self.replays = 0
+        if capture:
+            cur = torch.cuda.current_stream(dev)
+            s = torch.cuda.Stream(dev)
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                model._decode_step(self.state)          # warm-up: allocations, lazily set kernel attributes
+            cur.wait_stream(s)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=s):
+                model._decode_step(self.state)
+
+    def step(self) -> None:
+        if self.graph is not None:
+            self.graph.replay()
+            self.replays += 1
+        else:
+            self.model._decode_step(self.state)

@@ -84,9 +84,10 @@ def _declare(l: ctypes.CDLL) -> None:
     sig("dlamd_ctc_collapse", [vp, vp, vp, vp, vp, vp, vp, i, i, i, vp])
     sig("dlamd_lstm_bidir", [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, vp])
     sig("dlamd_layernorm", [vp, vp, vp, vp, vp, ll, i, f, i, vp])
-    sig("dlamd_attention_fwd", [vp, vp, vp, vp, vp, i, i, i, i, i, ll, ll, ll, ll, f, i, vp])
+    sig("dlamd_attention_fwd", [vp, vp, vp, vp, i, i, i, i, ll, ll, ll, ll, ll, ll, ll, ll, f, i, vp])
+    sig("dlamd_attention_decode", [vp, ll, vp, vp, ll, ll, vp, vp, ll, vp, i, i, vp, ll, i, i, f, vp])
     sig("dlamd_ctc_loss", [vp, i, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp])
     sig("dlamd_adamw", [vp, vp, vp, vp, vp, ll, f, f, f, f, f, f, f, vp, vp])
     sig("dlamd_sumsq", [vp, ll, vp, vp])
     sig("dlamd_jpeg_decode", [vp, i, i, ll, vp])
-    sig("dlamd_embed_rows", [vp, vp, vp, vp, ll, i, i, i, vp])
+    sig("dlamd_embed_rows", [vp, vp, vp, vp, vp, ll, i, i, i, i, f, vp])
