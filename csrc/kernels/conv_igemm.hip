@@ -331,7 +331,19 @@ static int dispatch(ConvArgs& a, hipStream_t stream, int cfg) {
     else if (a.Cout <= 64) bn = 64;
     else bn = 128;
   }
+  if (cfg == 0) {
+    // Small-M GEMMs (decoder steps: M = batch) would launch a handful of 128-row tiles on 256 CUs and
+    // run latency-bound; shrink the tile until the grid covers the chip (weights are then streamed by
+    // many CUs in parallel, x stays L2-resident).
+    const long long t128 = (long long)((a.M + 127) / 128) * ((a.Cout + bn - 1) / bn);
+    if (t128 < 160 && a.Cout >= 32) {
+      const long long t64 = (long long)((a.M + 63) / 64) * ((a.Cout + 63) / 64);
+      bn = (t64 >= 160 || a.Cout < 64) ? 1064 : 2032;
+      if (a.Cout < 64) bn = 2032;
+    }
+  }
   switch (bn) {
+    case 2032: return launch_cfg<32, 32, 2, 2, IS_1X1>(a, stream);
     case 16: return launch_cfg<128, 16, 4, 1, IS_1X1>(a, stream);
     case 32: return launch_cfg<128, 32, 4, 1, IS_1X1>(a, stream);
     case 64: return launch_cfg<128, 64, 2, 2, IS_1X1>(a, stream);

@@ -227,17 +227,19 @@ extern "C" int dlamd_attention_fwd(const void* q, const void* k, const void* v, 
 // One query per (b, h).  Keys/values: cache [B, Tcap, H*64] (strides given).  If knew/vnew are given, the new
 // row is first appended at position *t_ptr (device-side step counter) and the query attends over [0, *t_ptr];
 // otherwise it attends over klen keys (cross-attention over the encoder memory).
-__global__ __launch_bounds__(64) void attention_decode_kernel(const bf16_t* __restrict__ q, long long q_bs,
-                                                              bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
-                                                              long long c_bs, long long c_ss,
-                                                              const bf16_t* __restrict__ knew,
-                                                              const bf16_t* __restrict__ vnew, long long n_bs,
-                                                              const int* __restrict__ t_ptr, int klen, int Tcap,
-                                                              bf16_t* __restrict__ o, long long o_bs, int H,
-                                                              float scale) {
+__global__ __launch_bounds__(256) void attention_decode_kernel(const bf16_t* __restrict__ q, long long q_bs,
+                                                               bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
+                                                               long long c_bs, long long c_ss,
+                                                               const bf16_t* __restrict__ knew,
+                                                               const bf16_t* __restrict__ vnew, long long n_bs,
+                                                               const int* __restrict__ t_ptr, int klen, int Tcap,
+                                                               bf16_t* __restrict__ o, long long o_bs, int H,
+                                                               float scale) {
   __shared__ float s_p[1024];
   __shared__ float s_q[ATT_D];
-  const int lane = threadIdx.x;
+  __shared__ float s_red[8];
+  __shared__ float s_o[4][ATT_D];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.x;
   const int b = bh / H, h = bh - b * H;
   bf16_t* kb = kc + (long long)b * c_bs + h * ATT_D;
@@ -245,17 +247,18 @@ __global__ __launch_bounds__(64) void attention_decode_kernel(const bf16_t* __re
   int n = klen;
   if (knew) {
     const int t = min(*t_ptr, Tcap - 1);
-    kb[(long long)t * c_ss + lane] = knew[(long long)b * n_bs + h * ATT_D + lane];
-    vb[(long long)t * c_ss + lane] = vnew[(long long)b * n_bs + h * ATT_D + lane];
+    if (tid < ATT_D) {
+      kb[(long long)t * c_ss + tid] = knew[(long long)b * n_bs + h * ATT_D + tid];
+      vb[(long long)t * c_ss + tid] = vnew[(long long)b * n_bs + h * ATT_D + tid];
+    }
     n = t + 1;
-    __syncthreads();   // single wave: orders the append before the reads below
   }
   n = min(n, 1024);
-  s_q[lane] = (float)q[(long long)b * q_bs + h * ATT_D + lane] * scale;
-  __syncthreads();
-  // phase 1: lanes over keys
+  if (tid < ATT_D) s_q[tid] = (float)q[(long long)b * q_bs + h * ATT_D + tid] * scale;
+  __syncthreads();   // also orders the append above before the cache reads below (same workgroup)
+  // phase 1: threads over keys
   float mx = ATT_NEG;
-  for (int k = lane; k < n; k += 64) {
+  for (int k = tid; k < n; k += 256) {
     const bf16_t* kr = kb + (long long)k * c_ss;
     float acc = 0.f;
 #pragma unroll
@@ -271,18 +274,28 @@ __global__ __launch_bounds__(64) void attention_decode_kernel(const bf16_t* __re
     mx = fmaxf(mx, acc);
   }
   mx = wave_reduce_max(mx);
+  if (lane == 0) s_red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
   float sum = 0.f;
-  for (int k = lane; k < n; k += 64) {
+  for (int k = tid; k < n; k += 256) {
     float e = __expf(s_p[k] - mx);
     s_p[k] = e;
     sum += e;
   }
   sum = wave_reduce_sum(sum);
+  if (lane == 0) s_red[4 + wave] = sum;
   __syncthreads();
-  // phase 2: lanes over head dims
+  sum = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+  // phase 2: lanes over head dims, the four waves split the keys
   float acc = 0.f;
-  for (int k = 0; k < n; ++k) acc += s_p[k] * (float)vb[(long long)k * c_ss + lane];
-  o[(long long)b * o_bs + h * ATT_D + lane] = (bf16_t)(acc / sum);
+  for (int k = wave; k < n; k += 4) acc += s_p[k] * (float)vb[(long long)k * c_ss + lane];
+  s_o[wave][lane] = acc;
+  __syncthreads();
+  if (tid < ATT_D) {
+    const float tot = s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid];
+    o[(long long)b * o_bs + h * ATT_D + tid] = (bf16_t)(tot / sum);
+  }
 }
 
 extern "C" int dlamd_attention_decode(const void* q, long long q_bs, void* kc, void* vc, long long c_bs,
@@ -295,7 +308,7 @@ extern "C" int dlamd_attention_decode(const void* q, long long q_bs, void* kc, v
   if (!knew && (klen <= 0 || klen > 1024)) return -3;
   if (knew && (Tcap <= 0 || Tcap > 1024)) return -4;
   if (c_ss % 8 != 0 || c_bs % 8 != 0 || ((uintptr_t)kc & 15)) return -5;
-  hipLaunchKernelGGL(attention_decode_kernel, dim3(B * H), dim3(64), 0, stream, (const bf16_t*)q, q_bs, (bf16_t*)kc,
+  hipLaunchKernelGGL(attention_decode_kernel, dim3(B * H), dim3(256), 0, stream, (const bf16_t*)q, q_bs, (bf16_t*)kc,
                      (bf16_t*)vc, c_bs, c_ss, (const bf16_t*)knew, (const bf16_t*)vnew, n_bs, (const int*)t_ptr, klen,
                      Tcap, (bf16_t*)o, o_bs, H, scale);
   return DLAMD_CHECK_LAUNCH();

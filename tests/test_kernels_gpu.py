@@ -46,9 +46,11 @@ def test_conv_matches_reference(case):
     w = _rand_bf16(Cout, k, k, Cin, scale=(2.0 / (k * k * Cin)) ** 0.5, seed=2)
     b = torch.randn(Cout, generator=torch.Generator().manual_seed(3)) * 0.1
     ref = C.conv2d_nhwc_reference(x, w, b, stride=s, padding=p, act=act, out_dtype=torch.float32)
-    out = C.conv2d_nhwc(x.to(DEV), w.to(DEV), b.to(DEV), stride=s, padding=p, act=act)
-    assert out.shape == ref.shape
-    _close(out, ref)
+    # cfg 0 = the dispatcher's own choice; the explicit ids force every tile shape onto every problem
+    for cfg in (0, 16, 32, 64, 128, 1064, 1128, 2032):
+        out = C.conv2d_nhwc(x.to(DEV), w.to(DEV), b.to(DEV), stride=s, padding=p, act=act, cfg=cfg)
+        assert out.shape == ref.shape
+        _close(out, ref)
 
 
 def test_conv_asymmetric_kernel_and_stride():
