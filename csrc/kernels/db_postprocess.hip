@@ -92,63 +92,101 @@ __global__ void ccl_assign_kernel(int* __restrict__ parent_all, int* __restrict_
 }
 
 // stats layout per component: [xmin, ymin, xmax, ymax, count, sum(prob) as float bits]
-__global__ void ccl_stats_kernel(const bf16_t* __restrict__ prob, const int* __restrict__ parent_all,
-                                 const int* __restrict__ comp_id_all, int* __restrict__ stats, int H, int W,
-                                 int maxc) {
-  int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  int b = blockIdx.z;
+//
+// Contention control, three levels deep (a text blob is wide and many rows tall, so naive per-pixel
+// atomics all hit the same six words):
+//   1. lanes of a wave that see the same component are combined in registers (shuffles),
+//   2. the wave leaders of a 64 x 16 pixel block merge into a small LDS hash table (LDS atomics),
+//   3. one global atomic set per (block, component) is issued at the end.
+#define STAT_SLOTS 64
+#define STAT_ROWS 16
+
+__device__ __forceinline__ void stats_global_add(int* __restrict__ s, int xmin, int ymin, int xmax, int ymax, int cnt,
+                                                 float ps) {
+  atomicMin(&s[0], xmin);
+  atomicMin(&s[1], ymin);
+  atomicMax(&s[2], xmax);
+  atomicMax(&s[3], ymax);
+  atomicAdd(&s[4], cnt);
+  atomicAdd(reinterpret_cast<float*>(&s[5]), ps);
+}
+
+__global__ __launch_bounds__(256) void ccl_stats_kernel(const bf16_t* __restrict__ prob, const int* __restrict__ parent_all,
+                                                        const int* __restrict__ comp_id_all, int* __restrict__ stats,
+                                                        int H, int W, int maxc) {
+  __shared__ int t_cid[STAT_SLOTS];
+  __shared__ int t_xmin[STAT_SLOTS], t_ymin[STAT_SLOTS], t_xmax[STAT_SLOTS], t_ymax[STAT_SLOTS], t_cnt[STAT_SLOTS];
+  __shared__ float t_ps[STAT_SLOTS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < STAT_SLOTS) {
+    t_cid[tid] = -1; t_xmin[tid] = 0x7fffffff; t_ymin[tid] = 0x7fffffff; t_xmax[tid] = -1; t_ymax[tid] = -1;
+    t_cnt[tid] = 0; t_ps[tid] = 0.f;
+  }
+  __syncthreads();
+  const int x = blockIdx.x * 64 + lane;
+  const int b = blockIdx.z;
   const long long base = (long long)b * H * W;
   const int* parent = parent_all + base;
-  bool inb = (x < W && y < H);
-  int p = y * W + x;
-  int cid = -1;
-  float pv = 0.f;
-  if (inb) {
-    int root = parent[p];
-    if (root >= 0) {
-      // after ccl_assign every parent is either the root or one hop from it
-      int r2 = parent[root];
-      if (r2 != root) { root = r2; int r3 = parent[root]; while (r3 != root) { root = r3; r3 = parent[root]; } }
-      cid = comp_id_all[base + root];
-      pv = (float)prob[base + p];
+  for (int r = 0; r < STAT_ROWS / 4; ++r) {
+    const int y = blockIdx.y * STAT_ROWS + r * 4 + wave;
+    const bool inb = (x < W && y < H);
+    const int p = y * W + x;
+    int cid = -1;
+    float pv = 0.f;
+    if (inb) {
+      int root = parent[p];
+      if (root >= 0) {
+        // after ccl_assign every parent is either the root or one hop from it
+        int r2 = parent[root];
+        if (r2 != root) { root = r2; int r3 = parent[root]; while (r3 != root) { root = r3; r3 = parent[root]; } }
+        cid = comp_id_all[base + root];
+        pv = (float)prob[base + p];
+      }
     }
-  }
-  // wave-level combine of lanes with the same component
-  bool active = (cid >= 0 && cid < maxc);
-  int xmin = x, xmax = x, ymin = y, ymax = y, cnt = 1;
-  float ps = pv;
-  unsigned long long todo = __ballot(active);
-  while (todo) {
-    int leader = __ffsll((long long)todo) - 1;
-    int lc = __shfl(cid, leader, 64);
-    bool same = active && (cid == lc);
-    unsigned long long grp = __ballot(same);
-    // reduce over the group (all lanes participate in shuffles; non-members contribute identities)
-    int vxmin = same ? xmin : 0x7fffffff, vxmax = same ? xmax : -1;
-    int vymin = same ? ymin : 0x7fffffff, vymax = same ? ymax : -1;
-    int vcnt = same ? cnt : 0;
-    float vps = same ? ps : 0.f;
+    const bool active = (cid >= 0 && cid < maxc);
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int lc = __shfl(cid, leader, 64);
+      const bool same = active && (cid == lc);
+      const unsigned long long grp = __ballot(same);
+      int vxmin = same ? x : 0x7fffffff, vxmax = same ? x : -1;
+      int vcnt = same ? 1 : 0;
+      float vps = same ? pv : 0.f;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      vxmin = min(vxmin, __shfl_xor(vxmin, o, 64));
-      vxmax = max(vxmax, __shfl_xor(vxmax, o, 64));
-      vymin = min(vymin, __shfl_xor(vymin, o, 64));
-      vymax = max(vymax, __shfl_xor(vymax, o, 64));
-      vcnt += __shfl_xor(vcnt, o, 64);
-      vps += __shfl_xor(vps, o, 64);
+      for (int o = 32; o > 0; o >>= 1) {
+        vxmin = min(vxmin, __shfl_xor(vxmin, o, 64));
+        vxmax = max(vxmax, __shfl_xor(vxmax, o, 64));
+        vcnt += __shfl_xor(vcnt, o, 64);
+        vps += __shfl_xor(vps, o, 64);
+      }
+      if (lane == leader) {
+        // insert / merge into the block's LDS table (open addressing, linear probing)
+        int slot = (int)(((unsigned)lc * 2654435761u) >> 26) & (STAT_SLOTS - 1);
+        bool done = false;
+        for (int probe = 0; probe < STAT_SLOTS && !done; ++probe) {
+          const int cur = atomicCAS(&t_cid[slot], -1, lc);
+          if (cur == -1 || cur == lc) {
+            atomicMin(&t_xmin[slot], vxmin);
+            atomicMax(&t_xmax[slot], vxmax);
+            atomicMin(&t_ymin[slot], y);
+            atomicMax(&t_ymax[slot], y);
+            atomicAdd(&t_cnt[slot], vcnt);
+            atomicAdd(&t_ps[slot], vps);
+            done = true;
+          }
+          slot = (slot + 1) & (STAT_SLOTS - 1);
+        }
+        // more than STAT_SLOTS distinct components inside one 64 x 16 block (salt-and-pepper masks): go direct
+        if (!done) stats_global_add(stats + ((long long)b * maxc + lc) * 6, vxmin, y, vxmax, y, vcnt, vps);
+      }
+      todo &= ~grp;
     }
-    if ((int)(threadIdx.x & 63) == leader) {
-      int* s = stats + ((long long)b * maxc + lc) * 6;
-      atomicMin(&s[0], vxmin);
-      atomicMin(&s[1], vymin);
-      atomicMax(&s[2], vxmax);
-      atomicMax(&s[3], vymax);
-      atomicAdd(&s[4], vcnt);
-      atomicAdd(reinterpret_cast<float*>(&s[5]), vps);
-    }
-    todo &= ~grp;
   }
+  __syncthreads();
+  if (tid < STAT_SLOTS && t_cid[tid] >= 0)
+    stats_global_add(stats + ((long long)b * maxc + t_cid[tid]) * 6, t_xmin[tid], t_ymin[tid], t_xmax[tid], t_ymax[tid],
+                     t_cnt[tid], t_ps[tid]);
 }
 
 __global__ void stats_init_kernel(int* __restrict__ stats, int* __restrict__ ncomp, int* __restrict__ nbox, int n,
@@ -211,7 +249,8 @@ extern "C" int dlamd_db_postprocess(const void* mask, const void* prob, void* pa
   hipLaunchKernelGGL(ccl_merge_kernel, grid, dim3(256), 0, stream, (const uint8_t*)mask, (int*)parent, H, W);
   hipLaunchKernelGGL(ccl_assign_kernel, grid, dim3(256), 0, stream, (int*)parent, (int*)comp_id, (int*)ncomp, H, W,
                      maxc);
-  hipLaunchKernelGGL(ccl_stats_kernel, grid, dim3(256), 0, stream, (const bf16_t*)prob, (const int*)parent,
+  dim3 grid_s((W + 63) / 64, (H + STAT_ROWS - 1) / STAT_ROWS, B);
+  hipLaunchKernelGGL(ccl_stats_kernel, grid_s, dim3(256), 0, stream, (const bf16_t*)prob, (const int*)parent,
                      (const int*)comp_id, (int*)stats, H, W, maxc);
   hipLaunchKernelGGL(box_finalize_kernel, dim3((maxc + 255) / 256, B), dim3(256), 0, stream, (const int*)stats,
                      (const int*)ncomp, page_scale, valid, boxes, (int*)nbox, maxc, max_boxes, box_thresh,

@@ -77,7 +77,7 @@ def _declare(l: ctypes.CDLL) -> None:
             fn.argtypes = args
             fn.restype = ctypes.c_int
 
-    sig("dlamd_conv2d", [vp, vp, vp, vp, vp, vp] + [i] * 20 + [f, i, vp])
+    sig("dlamd_conv2d", [vp, vp, vp, vp, vp, vp] + [i] * 20 + [f, i, vp, vp])
     sig("dlamd_resample", [vp, i, vp, i, i, f, f, f, f, f, f, vp])
     sig("dlamd_db_postprocess", [vp] * 10 + [i, i, i, i, i, f, f, i, vp])
     sig("dlamd_row_argmax", [vp, i, vp, vp, ll, i, ll, vp])

@@ -27,6 +27,30 @@ RES_NONE, RES_SAME, RES_UP2 = 0, 1, 2
 
 IntPair = Union[int, Tuple[int, int]]
 
+USE_WEIGHT_FRAGMENTS = True
+
+
+def weight_fragments(w: torch.Tensor) -> torch.Tensor:
+    """[Cout, kh, kw, Cin] bf16 -> [Npad/16, Kpad/32, 64, 8]: lane l of a wave holds rows n = 16*tile + (l & 15),
+    k = 32*step + 8*(l >> 4) .. +8 - exactly the A operand of ``mfma_f32_16x16x32_bf16``, so the kernel reads
+    weights straight from L2 into registers as contiguous 1 KiB wave loads (no LDS staging for weights).
+    N is padded to a multiple of 128 and K to a multiple of 64 with zeros (no bounds checks in the kernel)."""
+    # cached on the tensor OBJECT (module weights persist; a data_ptr key could be recycled by the allocator)
+    cached = getattr(w, "_dlamd_frag", None)
+    if cached is not None and cached[0] == w._version:
+        return cached[1]
+    Cout = w.shape[0]
+    K = w.numel() // Cout
+    Np, Kp = (Cout + 127) // 128 * 128, (K + 63) // 64 * 64
+    w2 = torch.zeros((Np, Kp), dtype=torch.bfloat16, device=w.device)
+    w2[:Cout, :K] = w.reshape(Cout, K)
+    f = w2.view(Np // 16, 16, Kp // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(Np // 16, Kp // 32, 64, 8)
+    try:
+        w._dlamd_frag = (w._version, f)
+    except Exception:  # noqa: BLE001 - e.g. tensors that refuse attributes; just rebuild next time
+        pass
+    return f
+
 
 def _pair(v: IntPair) -> Tuple[int, int]:
     return (v, v) if isinstance(v, int) else (int(v[0]), int(v[1]))
@@ -108,6 +132,7 @@ def conv2d_nhwc(
     thr: float = 0.3,
     out_dtype: torch.dtype = torch.bfloat16,
     cfg: int = 0,
+    wfrag: Optional[torch.Tensor] = None,
 ):
     """Fused conv (+bias +residual +activation) on NHWC bf16 tensors.
 
@@ -179,7 +204,9 @@ def conv2d_nhwc(
         _loader.ptr(y), _loader.ptr(mask),
         B, H, W, Cin, x_cstride, Cout, kh, kw, sh, sw, ph, pw,
         ACT[act], res_mode, res_cstride, out_mode, out_f, y_cstride, y_coff,
-        1 if out_dtype == torch.float32 else 0, float(thr), cfg, _loader.stream_ptr(),
+        1 if out_dtype == torch.float32 else 0, float(thr), cfg,
+        _loader.ptr(wfrag if wfrag is not None else weight_fragments(w)) if USE_WEIGHT_FRAGMENTS else None,
+        _loader.stream_ptr(),
     )
     _loader.check(rc, "dlamd_conv2d")
     if out_mode == OUT_PROB:
@@ -207,6 +234,6 @@ def linear_bf16(
     r2 = None if res is None else res.reshape(1, 1, -1, N)
     y = conv2d_nhwc(
         x2, w.view(N, 1, 1, K), bias, act=act, res=r2, res_mode=RES_SAME if res is not None else RES_NONE,
-        out_dtype=out_dtype,
+        out_dtype=out_dtype, wfrag=weight_fragments(w) if (x.is_cuda and USE_WEIGHT_FRAGMENTS) else None,
     )
     return y.reshape(*lead, N)

@@ -47,10 +47,43 @@ def test_conv_matches_reference(case):
     b = torch.randn(Cout, generator=torch.Generator().manual_seed(3)) * 0.1
     ref = C.conv2d_nhwc_reference(x, w, b, stride=s, padding=p, act=act, out_dtype=torch.float32)
     # cfg 0 = the dispatcher's own choice; the explicit ids force every tile shape onto every problem
-    for cfg in (0, 16, 32, 64, 128, 1064, 1128, 2032):
+    cfgs = [0, 16, 32, 64, 128, 1064, 1128, 2032, 3900]
+    if k == 3 and p == 1 and s == 1 and Cin % 64 == 0:
+        cfgs += [3064, 3128]          # LDS-patch 3x3 kernel, both channel-tile widths
+    for cfg in cfgs:
         out = C.conv2d_nhwc(x.to(DEV), w.to(DEV), b.to(DEV), stride=s, padding=p, act=act, cfg=cfg)
         assert out.shape == ref.shape
         _close(out, ref)
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 70, 64, 128, (1, 1)), (3, 12, 45, 128, 256, (2, 1)), (2, 6, 130, 256, 64, (2, 1)),
+                                   (1, 3, 200, 64, 512, (1, 1)), (2, 37, 29, 64, 64, (1, 1)), (1, 5, 17, 192, 96, (2, 1))])
+@pytest.mark.parametrize("cfg", [3064, 3128])
+def test_conv3x3_patch_kernel_shapes_strides_and_fusions(shape, cfg):
+    """Every tile shape of the patch kernel (8x16 / 4x32 / 2x64 / 1x128 by output height), ragged edges,
+    stride (2,1), fused residual + ReLU, and the replicate-into-concat store."""
+    B, H, W, Cin, Cout, stride = shape
+    x = _rand_bf16(B, H, W, Cin, seed=21)
+    w = _rand_bf16(Cout, 3, 3, Cin, scale=(2.0 / (9 * Cin)) ** 0.5, seed=22)
+    b = torch.randn(Cout, generator=torch.Generator().manual_seed(23)) * 0.1
+    Ho, Wo = C.out_hw(H, W, 3, 3, stride[0], stride[1], 1, 1)
+    res = _rand_bf16(B, Ho, Wo, Cout, seed=24)
+    ref = C.conv2d_nhwc_reference(x, w, b, stride=stride, padding=1, act="relu", res=res, res_mode=C.RES_SAME,
+                                  out_dtype=torch.float32)
+    out = C.conv2d_nhwc(x.to(DEV), w.to(DEV), b.to(DEV), stride=stride, padding=1, act="relu", res=res.to(DEV),
+                        res_mode=C.RES_SAME, cfg=cfg)
+    _close(out, ref)
+    gen = C.conv2d_nhwc(x.to(DEV), w.to(DEV), b.to(DEV), stride=stride, padding=1, act="relu", res=res.to(DEV),
+                        res_mode=C.RES_SAME, cfg=3900)
+    _close(out, gen.float().cpu(), rtol=1e-2, atol=1e-2)      # same maths as the generic kernel
+    if Cout % 16 == 0:
+        ref2 = C.conv2d_nhwc_reference(x, w, None, stride=stride, padding=1, out_mode=C.OUT_REPLICATE, out_f=2,
+                                       out_dtype=torch.float32)
+        cat = torch.zeros(B, 2 * Ho, 2 * Wo, Cout + 32, dtype=torch.bfloat16, device=DEV)
+        C.conv2d_nhwc(x.to(DEV), w.to(DEV), None, stride=stride, padding=1, out_mode=C.OUT_REPLICATE, out_f=2, out=cat,
+                      out_coff=16, cfg=cfg)
+        _close(cat[..., 16 : 16 + Cout], ref2)
+        assert cat[..., :16].abs().max().item() == 0 and cat[..., 16 + Cout :].abs().max().item() == 0
 
 
 def test_conv_asymmetric_kernel_and_stride():
