@@ -132,11 +132,14 @@ __device__ __forceinline__ void conv_epilogue_pixel(const ConvArgs& p, const f32
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool IS_1X1, bool B_DIRECT>
+template <int BM, int BN, int WM, int WN, bool IS_1X1, bool B_DIRECT, int BKT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int FM = TM / 16, FN = TN / 16;
-  constexpr int PA = (BM + 31) / 32, PB = (BN + 31) / 32;
+  // K tile of BKT elements: LDS rows of ROWB bytes = CH 16-byte chunks, XOR-swizzled with the row index;
+  // 256 threads cover RP rows per pass.  BKT = 128 halves the barriers (and exposed load latencies) per FLOP.
+  constexpr int ROWB = BKT * 2, CH = BKT / 8, RP = 256 / CH, KS = BKT / 32;
+  constexpr int PA = (BM + RP - 1) / RP, PB = (BN + RP - 1) / RP;
   static_assert(WM * WN == 4, "4 waves");
   static_assert(TM % 16 == 0 && TN % 16 == 0, "tile");
 
@@ -146,9 +149,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   // K-tile ahead.  That halves the LDS footprint of a block (twice the blocks per CU - this kernel lives on
   // occupancy to hide global-load latency) and removes the weight LDS write + read passes.
   constexpr int LB = B_DIRECT ? 0 : BN;
-  char* As = smem;                            // nbuf x BM x 128 B
-  char* Bs = smem + p.nbuf * BM * 128;        // nbuf x BN x 128 B (unused with B_DIRECT)
-  uint32_t* ktab = reinterpret_cast<uint32_t*>(smem + p.nbuf * (BM + LB) * 128);
+  char* As = smem;                            // nbuf x BM x ROWB
+  char* Bs = smem + p.nbuf * BM * ROWB;        // nbuf x BN x 128 B (unused with B_DIRECT)
+  uint32_t* ktab = reinterpret_cast<uint32_t*>(smem + p.nbuf * (BM + LB) * ROWB);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -160,14 +163,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   const int tn = tile % p.tiles_n;
   const int tm = tile / p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int nkt = (p.K + BK - 1) / BK;
+  const int nkt = (p.K + BKT - 1) / BKT;
 
-  const int c = tid & 7;        // 16-byte chunk inside the 128-byte K row
-  const int r0 = tid >> 3;      // 0..31
+  const int c = tid % CH;       // 16-byte chunk inside the K row
+  const int r0 = tid / CH;      // 0..RP-1
 
   if (!IS_1X1) {
     // (tap, cin) decomposition of every 8-wide K chunk, once per block.
-    for (int e = tid; e < nkt * 8; e += 256) {
+    for (int e = tid; e < nkt * CH; e += 256) {
       int k = e * 8;
       uint32_t t = 0xFFFFFFFFu, off = 0;
       if (k < p.K) {
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   bool a_ok[PA];
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
-    int r = r0 + 32 * i;
+    int r = r0 + RP * i;
     int m = m0 + r;
     bool ok = (r < BM) && (m < p.M);
     int mm = ok ? m : 0;
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   bool b_ok[PB];
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
-    int r = r0 + 32 * i;
+    int r = r0 + RP * i;
     int n = n0 + r;
     b_ok[i] = (r < BN) && (n < p.Cout);
     b_base[i] = (long long)(b_ok[i] ? n : 0) * p.K;
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   u32x4 a_reg[PA], b_reg[PB];
 
   auto load_tile = [&](int kt) {
-    int k = kt * BK + c * 8;
+    int k = kt * BKT + c * 8;
     bool kok;
     int dy = 0, dx = 0;
     long long off;
@@ -225,11 +228,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       kok = k < p.K;
       off = k;
     } else {
-      uint32_t t = ktab[2 * (kt * 8 + c)];
+      uint32_t t = ktab[2 * (kt * CH + c)];
       kok = t != 0xFFFFFFFFu;
       dy = int(t >> 8);
       dx = int(t & 0xff);
-      off = (long long)ktab[2 * (kt * 8 + c) + 1];
+      off = (long long)ktab[2 * (kt * CH + c) + 1];
     }
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
@@ -256,16 +259,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-      int r = r0 + 32 * i;
-      if (BM % 32 == 0 || r < BM)
-        *reinterpret_cast<u32x4*>(As + buf * BM * 128 + r * 128 + ((c ^ (r & 7)) << 4)) = a_reg[i];
+      int r = r0 + RP * i;
+      if (BM % RP == 0 || r < BM)
+        *reinterpret_cast<u32x4*>(As + buf * BM * ROWB + r * ROWB + ((c ^ (r & (CH - 1))) << 4)) = a_reg[i];
     }
     if (!B_DIRECT) {
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
-        int r = r0 + 32 * i;
-        if (BN % 32 == 0 || r < BN)
-          *reinterpret_cast<u32x4*>(Bs + buf * BN * 128 + r * 128 + ((c ^ (r & 7)) << 4)) = b_reg[i];
+        int r = r0 + RP * i;
+        if (BN % RP == 0 || r < BN)
+          *reinterpret_cast<u32x4*>(Bs + buf * BN * ROWB + r * ROWB + ((c ^ (r & (CH - 1))) << 4)) = b_reg[i];
       }
     }
   };
@@ -280,12 +283,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   const int fq = lane >> 4;
 
   // direct weight fragments: wcur = tile kt, wnxt = tile kt+1 (in flight during the MFMAs of tile kt)
-  bf16x8 wcur[2][FN], wnxt[2][FN];
+  bf16x8 wcur[KS][FN], wnxt[KS][FN];
   const bf16_t* wfp = nullptr;
   if (B_DIRECT) {
     wfp = p.wfrag + ((long long)(n0 / 16 + wn * FN) * p.k32 * 64 + lane) * 8;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int i = 0; i < FN; ++i)
         wcur[ks][i] = *reinterpret_cast<const bf16x8*>(wfp + ((long long)i * p.k32 + ks) * 512);
@@ -301,16 +304,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       load_tile(kt + 1);
       if (B_DIRECT) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
           for (int i = 0; i < FN; ++i)
-            wnxt[ks][i] = *reinterpret_cast<const bf16x8*>(wfp + ((long long)i * p.k32 + (kt + 1) * 2 + ks) * 512);
+            wnxt[ks][i] = *reinterpret_cast<const bf16x8*>(wfp + ((long long)i * p.k32 + (kt + 1) * KS + ks) * 512);
       }
     }
-    const char* Ab = As + buf * BM * 128;
-    const char* Bb = Bs + buf * BN * 128;
+    const char* Ab = As + buf * BM * ROWB;
+    const char* Bb = Bs + buf * BN * ROWB;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       bf16x8 wf[FN], xf[FM];
       const int chunk = ks * 4 + fq;
 #pragma unroll
@@ -319,13 +322,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
           wf[i] = wcur[ks][i];
         } else {
           int row = wn * TN + i * 16 + frow;
-          wf[i] = *reinterpret_cast<const bf16x8*>(Bb + row * 128 + ((chunk ^ (row & 7)) << 4));
+          wf[i] = *reinterpret_cast<const bf16x8*>(Bb + row * ROWB + ((chunk ^ (row & (CH - 1))) << 4));
         }
       }
 #pragma unroll
       for (int j = 0; j < FM; ++j) {
         int row = wm * TM + j * 16 + frow;
-        xf[j] = *reinterpret_cast<const bf16x8*>(Ab + row * 128 + ((chunk ^ (row & 7)) << 4));
+        xf[j] = *reinterpret_cast<const bf16x8*>(Ab + row * ROWB + ((chunk ^ (row & (CH - 1))) << 4));
       }
 #pragma unroll
       for (int i = 0; i < FN; ++i)
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       store_tile(buf ^ 1);
       if (B_DIRECT) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
           for (int i = 0; i < FN; ++i) wcur[ks][i] = wnxt[ks][i];
       }
@@ -540,15 +543,15 @@ static int dispatch_patch(ConvArgs& a, hipStream_t stream) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool IS_1X1, bool B_DIRECT>
+template <int BM, int BN, int WM, int WN, bool IS_1X1, bool B_DIRECT, int BKT>
 static int launch_impl(ConvArgs& a, hipStream_t stream) {
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.Cout + BN - 1) / BN;
-  const int nkt = (a.K + BK - 1) / BK;
+  const int nkt = (a.K + BKT - 1) / BKT;
   // K <= 64 (1x1 laterals, deconvs): one K tile, no double buffer -> half the LDS, twice the blocks per CU.
   a.nbuf = nkt == 1 ? 1 : 2;
-  size_t smem = a.nbuf * (BM + (B_DIRECT ? 0 : BN)) * 128 + (IS_1X1 ? 0 : size_t(nkt) * 8 * 2 * sizeof(uint32_t));
-  auto kern = conv_igemm_kernel<BM, BN, WM, WN, IS_1X1, B_DIRECT>;
+  size_t smem = a.nbuf * (BM + (B_DIRECT ? 0 : BN)) * (BKT * 2) + (IS_1X1 ? 0 : size_t(nkt) * (BKT / 8) * 2 * sizeof(uint32_t));
+  auto kern = conv_igemm_kernel<BM, BN, WM, WN, IS_1X1, B_DIRECT, BKT>;
   static size_t max_set = 0;
   if (smem > 65536 && smem > max_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -564,8 +567,8 @@ static int launch_impl(ConvArgs& a, hipStream_t stream) {
 
 template <int BM, int BN, int WM, int WN, bool IS_1X1>
 static int launch_cfg(ConvArgs& a, hipStream_t stream) {
-  if (a.wfrag) return launch_impl<BM, BN, WM, WN, IS_1X1, true>(a, stream);
-  return launch_impl<BM, BN, WM, WN, IS_1X1, false>(a, stream);
+  if (a.wfrag) return launch_impl<BM, BN, WM, WN, IS_1X1, true, 64>(a, stream);
+  return launch_impl<BM, BN, WM, WN, IS_1X1, false, 64>(a, stream);
 }
 
 template <bool IS_1X1>
@@ -598,6 +601,10 @@ static int dispatch(ConvArgs& a, hipStream_t stream, int cfg) {
     case 128: return launch_cfg<128, 128, 2, 2, IS_1X1>(a, stream);
     case 1064: return launch_cfg<64, 64, 2, 2, IS_1X1>(a, stream);
     case 1128: return launch_cfg<64, 128, 1, 4, IS_1X1>(a, stream);
+    case 4128:   // 64 x 128 tile with a 128-deep K tile (needs fragment weights); measured: ties or loses to 1128
+                 // except on 512->512 (fewer barriers, but 132 VGPRs -> 3 waves/SIMD), so auto never picks it
+      if (!a.wfrag) return -14;
+      return launch_impl<64, 128, 1, 4, IS_1X1, true, 128>(a, stream);
     default: return -4;
   }
 }
@@ -609,7 +616,7 @@ extern "C" int dlamd_conv2d(const void* x, const void* w, const float* bias, con
                             hipStream_t stream) {
   ConvArgs a;
   a.wfrag = (const bf16_t*)wfrag;
-  a.k32 = (kh * kw * Cin + 63) / 64 * 2;
+  a.k32 = (kh * kw * Cin + 127) / 128 * 4;   // weight fragments are zero-padded to a multiple of 128 in K
   a.x = (const bf16_t*)x;
   a.w = (const bf16_t*)w;
   a.bias = bias;

@@ -114,6 +114,8 @@ class Settings:
     use_hip_graphs: bool = True
     node_id: str = field(default_factory=lambda: os.uname().nodename)
     fault_inject: str = ""
+    force_pool: bool = False         # use the worker-process pool even with a single GPU
+    cpu_model: str = "full"          # CPU oracle path model size: full | tiny (tests)
 
     @classmethod
     def from_env(cls, env: Optional[Mapping[str, str]] = None, dotenv: Optional[str] = None) -> "Settings":
@@ -144,6 +146,8 @@ class Settings:
             hbm_budget_gb=_get_float(e, "OCR_HBM_BUDGET_GB", 200.0),
             use_hip_graphs=_get_bool(e, "OCR_USE_HIP_GRAPHS", True),
             fault_inject=e.get("FAULT_INJECT", ""),
+            force_pool=_get_bool(e, "OCR_FORCE_POOL", False),
+            cpu_model=e.get("OCR_CPU_MODEL", "full"),
         )
         s.validate()
         return s

@@ -57,8 +57,10 @@ class DBNet(nn.Module):
         self.head2 = Deconv2x2(q, q, act="relu", bn=True)
         self.head3 = Deconv2x2(q, 1, act="sigmoid", bn=False)
         self.inner, self.q = inner, q
-        # prior-probability init (background ~0.1) so an untrained map is mostly background
+        # prior-probability init (focal-loss style): near-zero last-layer weights + bias -2.2 make an untrained
+        # network predict p ~ 0.1 everywhere, i.e. an empty mask - no hallucinated boxes before training
         with torch.no_grad():
+            self.head3.deconv.weight.mul_(1e-2)
             self.head3.deconv.bias.fill_(-2.2)
 
     # ------------------------------------------------------------------ training path (NCHW)

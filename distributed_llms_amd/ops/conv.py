@@ -34,14 +34,14 @@ def weight_fragments(w: torch.Tensor) -> torch.Tensor:
     """[Cout, kh, kw, Cin] bf16 -> [Npad/16, Kpad/32, 64, 8]: lane l of a wave holds rows n = 16*tile + (l & 15),
     k = 32*step + 8*(l >> 4) .. +8 - exactly the A operand of ``mfma_f32_16x16x32_bf16``, so the kernel reads
     weights straight from L2 into registers as contiguous 1 KiB wave loads (no LDS staging for weights).
-    N is padded to a multiple of 128 and K to a multiple of 64 with zeros (no bounds checks in the kernel)."""
+    N and K are padded to multiples of 128 with zeros (no bounds checks in the kernel)."""
     # cached on the tensor OBJECT (module weights persist; a data_ptr key could be recycled by the allocator)
     cached = getattr(w, "_dlamd_frag", None)
     if cached is not None and cached[0] == w._version:
         return cached[1]
     Cout = w.shape[0]
     K = w.numel() // Cout
-    Np, Kp = (Cout + 127) // 128 * 128, (K + 63) // 64 * 64
+    Np, Kp = (Cout + 127) // 128 * 128, (K + 127) // 128 * 128
     w2 = torch.zeros((Np, Kp), dtype=torch.bfloat16, device=w.device)
     w2[:Cout, :K] = w.reshape(Cout, K)
     f = w2.view(Np // 16, 16, Kp // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(Np // 16, Kp // 32, 64, 8)

@@ -214,3 +214,34 @@ def test_lstm_ragged_variants_match_reference(N):
     got = lstm.lstm_layer_ragged(x.to(DEV), p.to(DEV), lay_g).float().cpu()
     err = (got - ref).abs()
     assert err.max().item() < 0.06 and err.mean().item() < 4e-3, (err.max().item(), err.mean().item())
+
+
+def test_trained_weights_read_an_unseen_page():
+    """End-to-end accuracy with the shipped weights (train/page_trainer.py): scanned PDF of an unseen synthetic page
+    -> detector boxes -> crops -> CRNN -> text.  Skipped when no weights are shipped."""
+    import os
+    from pathlib import Path
+
+    from distributed_llms_amd.runtime.document import DocumentPipeline
+    from distributed_llms_amd.runtime.workers import build_engine
+    from distributed_llms_amd.train.trainer import _edit_distance
+
+    wd = Path(__file__).resolve().parents[1] / "weights"
+    if not (wd / "dbnet.safetensors").exists() or not (wd / "crnn.safetensors").exists():
+        pytest.skip("no trained weights shipped")
+    eng = build_engine("cuda:0", {"model": "full", "weights_dir": str(wd), "cfg": dict(max_batch_pages=2)})
+    pipe = DocumentPipeline(eng, decode_threads=2)
+    pages, truths = [], []
+    for seed in (777_001, 777_002):
+        pg, tr = synth.render_page(seed)
+        pages.append(pg)
+        truths.append(tr)
+    doc = pipe.process_pdf(synth.make_scanned_pdf(pages, codec="jpeg"), "acc")
+    assert doc.mode == "ocr"
+    for pr, tr in zip(doc.pages, truths):
+        assert abs(len(pr.lines) - len(tr.texts)) <= max(3, len(tr.texts) // 8), (len(pr.lines), len(tr.texts))
+        got = "\n".join(l.text for l in pr.lines)
+        want = "\n".join(tr.texts)
+        cer = _edit_distance(got, want) / max(len(want), 1)
+        assert cer < 0.10, (cer, got[:200], want[:200])
+    assert truths[0].texts[0].split()[0] in doc.text

@@ -47,7 +47,7 @@ def test_conv_matches_reference(case):
     b = torch.randn(Cout, generator=torch.Generator().manual_seed(3)) * 0.1
     ref = C.conv2d_nhwc_reference(x, w, b, stride=s, padding=p, act=act, out_dtype=torch.float32)
     # cfg 0 = the dispatcher's own choice; the explicit ids force every tile shape onto every problem
-    cfgs = [0, 16, 32, 64, 128, 1064, 1128, 2032, 3900]
+    cfgs = [0, 16, 32, 64, 128, 1064, 1128, 2032, 3900, 4128]    # 4xxx: 128-deep K tile
     if k == 3 and p == 1 and s == 1 and Cin % 64 == 0:
         cfgs += [3064, 3128]          # LDS-patch 3x3 kernel, both channel-tile widths
     for cfg in cfgs:

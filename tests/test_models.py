@@ -8,6 +8,9 @@ from distributed_llms_amd.models.dbnet import DBNet
 
 def _randomize_bn(model):
     g = torch.Generator().manual_seed(0)
+    if hasattr(model, "head3"):
+        with torch.no_grad():   # undo the prior-probability init so the probability map has real contrast
+            model.head3.deconv.weight.mul_(100.0)
     for m in model.modules():
         if isinstance(m, torch.nn.BatchNorm2d):
             m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
