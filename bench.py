@@ -10,11 +10,15 @@ scaling: 100 pages per GPU per step); the timed region is bracketed by a
 barrier + device synchronise on both sides and the per-rank times are
 MAX-reduced.
 
-Weights are random-init (no checkpoint is reachable offline) and the pages are
-synthetic (rendered text + scanner noise), exactly as BASELINE.json prescribes.
-A random-init detector emits no usable boxes, so the recognizer is fed the
-generator's ground-truth line boxes for each page (about 43 lines/page); the
-detector and its GPU post-process still run in full on every page.
+The pages are synthetic (rendered text + scanner noise), as BASELINE.json
+prescribes.  No public checkpoint is reachable offline, so the weights are the
+ones this repository trains itself on that page family (train/page_trainer.py,
+shipped under weights/): the detector finds the lines, the recognizer reads
+them, and the character error rate of the timed output against the generator's
+ground truth is reported next to the throughput.  With --random-init (or when
+weights/ is absent) the architecture runs with random weights; a random-init
+detector emits no usable boxes, so the recognizer is then fed the generator's
+line boxes (detector + post-process still run in full on every page).
 """
 from __future__ import annotations
 
@@ -53,6 +57,8 @@ def parse_args():
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--cpu", action="store_true", help="debug: tiny model on CPU")
     ap.add_argument("--stage-times", action="store_true")
+    ap.add_argument("--weights", default=str(ROOT / "weights"), help="directory with dbnet/crnn .safetensors")
+    ap.add_argument("--random-init", action="store_true", help="ignore trained weights")
     return ap.parse_args()
 
 
@@ -87,6 +93,16 @@ def main():
         rec = CRNN(hidden=64, widths=(16, 32, 32, 32, 64, 64))
         cfg.det_limit_side, cfg.rec_max_width, cfg.rec_width_quantum = 160, 256, 64
         size = (248, 350)
+    trained = (use_gpu and not args.random_init and os.path.exists(os.path.join(args.weights, "dbnet.safetensors"))
+               and os.path.exists(os.path.join(args.weights, "crnn.safetensors")))
+    if trained:
+        from distributed_llms_amd.models.crnn import CRNN
+        from distributed_llms_amd.models.dbnet import DBNet
+        from distributed_llms_amd.utils.weights import load_model_weights
+
+        det, rec = DBNet(), CRNN()
+        load_model_weights(det, os.path.join(args.weights, "dbnet.safetensors"), strict=False)
+        load_model_weights(rec, os.path.join(args.weights, "crnn.safetensors"), strict=False)
     engine = OcrEngine(device, det, rec, cfg, seed=1234)
     pipe = DocumentPipeline(engine)
 
@@ -95,8 +111,9 @@ def main():
     rendered = [synth.render_page(1000 * rank + i, size=size, font_px=42 if use_gpu else 10,
                                   margin=220 if use_gpu else 16) for i in range(n_dist)]
     pages = [rendered[i % n_dist][0] for i in range(args.pages_per_doc)]
-    priors = [rendered[i % n_dist][1].boxes for i in range(args.pages_per_doc)]
-    lines_per_page = float(np.mean([len(p) for p in priors]))
+    truth_boxes = [rendered[i % n_dist][1].boxes for i in range(args.pages_per_doc)]
+    lines_per_page = float(np.mean([len(p) for p in truth_boxes]))
+    priors = None if trained else truth_boxes      # trained detector: no hints of any kind
     if args.input == "pdf":
         enc = None
         if args.codec == "jpeg":
@@ -135,6 +152,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    cer = None
+    if trained and rank == 0:   # accuracy of the timed output (outside the timed region)
+        from distributed_llms_amd.train.trainer import _edit_distance
+
+        ed = nch = 0
+        for i, pg in enumerate(doc.pages):
+            want = "\n".join(rendered[i % n_dist][1].texts)
+            got = "\n".join(ln.text for ln in pg.lines)
+            ed += _edit_distance(got, want)
+            nch += len(want)
+        cer = ed / max(nch, 1)
+
     if rank == 0:
         total_pages = args.steps * args.pages_per_doc * world
         out = {
@@ -149,10 +178,13 @@ def main():
             "scaling": "weak",
             "vs_baseline": round(total_pages / dt / CPU_PROXY_PAGES_PER_S, 1),
             "dtype": "bf16" if use_gpu else "fp32-cpu-debug",
-            "data": ("synthetic 300-DPI A4 scanned PDF (rendered text + noise, %s page images), random-init weights; "
-                     "recognizer fed the generator's ground-truth line boxes because a random-init detector "
-                     "finds none (detector + post-process still run on every page)" % args.codec)
-            if args.input == "pdf" else "synthetic decoded 300-DPI A4 rasters, random-init weights",
+            "data": (("synthetic 300-DPI A4 scanned PDF (rendered text + noise, %s page images); weights trained in-repo "
+                      "on this synthetic page family (train/page_trainer.py), detector boxes used as found" % args.codec)
+                     if trained else
+                     ("synthetic 300-DPI A4 scanned PDF (rendered text + noise, %s page images), random-init weights; "
+                      "recognizer fed the generator's ground-truth line boxes because a random-init detector "
+                      "finds none (detector + post-process still run on every page)" % args.codec))
+            if args.input == "pdf" else "synthetic decoded 300-DPI A4 rasters",
             "config": {
                 "model": "DBNet-R18 (1344x960 det input) + CRNN (2xBiLSTM-256, h=48) + CTC greedy",
                 "global_batch": args.pages_per_doc * world,
@@ -165,6 +197,8 @@ def main():
                 "input": args.input,
                 "p50_extract_latency_ms": round(1000.0 * dt / args.steps, 1),
                 "lines_recognized": n_lines,
+                "weights": "trained (weights/)" if trained else "random-init",
+                "cer_vs_truth": None if cer is None else round(cer, 5),
                 "baseline": "CPU proxy: same graphs, torch CPU eager, ProcessPoolExecutor(8) on 8 vCPU = 0.84 pages/s "
                             "(BASELINE.md; the reference publishes no number)",
             },

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Recurrent-kernel microbenchmark: us per time step for the persistent BiLSTM variants.
 
-    DLAMD_LSTM_VARIANT={1,2,3} python bench/lstm_bench.py [N] [T]
+    python bench/lstm_bench.py [N] [T]        # every variant: 1 v1, 2 v2x16, 3 v2x32, 4 v3 (half of W_hh resident)
 """
 import os
 import sys
@@ -34,15 +34,17 @@ def main():
                                             None, _loader.ptr(y), N, T, H, 2, _loader.stream_ptr())
         assert rc == 0
 
-    run()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(5):
+    for variant in (0, 1, 2, 3, 4):
+        lstm.set_kernel_variant(variant)
         run()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / 5 * 1e3
-    print(f"variant={os.environ.get('DLAMD_LSTM_VARIANT', '0')} N={N} T={T}: {ms:.3f} ms/launch, {ms * 1e3 / T:.2f} us/step",
-          flush=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 5 * 1e3
+        print(f"variant={variant} N={N} T={T}: {ms:.3f} ms/launch, {ms * 1e3 / T:.2f} us/step", flush=True)
+    lstm.set_kernel_variant(0)
 
 
 if __name__ == "__main__":

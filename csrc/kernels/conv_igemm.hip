@@ -44,6 +44,7 @@ struct ConvArgs {
   int nbuf;         // LDS operand buffers: 2 (double buffered K loop) or 1 when the whole K fits one tile
   const bf16_t* wfrag;  // weights pre-swizzled to MFMA fragment order [N/16][Kpad/32][64][8] (or nullptr)
   int k32;          // Kpad / 32
+  int n16;          // padded Cout / 16: 16-row weight tiles that exist in wfrag (tile reads are clamped to it)
 };
 
 static constexpr int BK = 64;  // K elements per tile (128 B per LDS row)
@@ -285,13 +286,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   // direct weight fragments: wcur = tile kt, wnxt = tile kt+1 (in flight during the MFMAs of tile kt)
   bf16x8 wcur[KS][FN], wnxt[KS][FN];
   const bf16_t* wfp = nullptr;
+  long long wtile[FN];
   if (B_DIRECT) {
-    wfp = p.wfrag + ((long long)(n0 / 16 + wn * FN) * p.k32 * 64 + lane) * 8;
+    wfp = p.wfrag + (long long)lane * 8;
+    // a tile wider than the padded weight matrix (BN = 256 on a 128-padded Cout) re-reads the last tile
+    // instead of running off the buffer; those channels are >= Cout and never stored
+#pragma unroll
+    for (int i = 0; i < FN; ++i) wtile[i] = (long long)min(n0 / 16 + wn * FN + i, p.n16 - 1) * p.k32 * 512;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int i = 0; i < FN; ++i)
-        wcur[ks][i] = *reinterpret_cast<const bf16x8*>(wfp + ((long long)i * p.k32 + ks) * 512);
+        wcur[ks][i] = *reinterpret_cast<const bf16x8*>(wfp + wtile[i] + (long long)ks * 512);
   }
 
   load_tile(0);
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
           for (int i = 0; i < FN; ++i)
-            wnxt[ks][i] = *reinterpret_cast<const bf16x8*>(wfp + ((long long)i * p.k32 + (kt + 1) * KS + ks) * 512);
+            wnxt[ks][i] = *reinterpret_cast<const bf16x8*>(wfp + wtile[i] + (long long)((kt + 1) * KS + ks) * 512);
       }
     }
     const char* Ab = As + buf * BM * ROWB;
@@ -447,12 +453,15 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const ConvArgs p) {
 
   // weights: fragment order [N/16][K/32][64][8], K = tap*Cin + cin.  K-step index of (tap, chunk cc, ks):
   //   (tap*Cin + cc*64 + ks*32) / 32 = tap*(Cin/32) + cc*2 + ks
-  const bf16_t* wfp = p.wfrag + ((long long)(n0 / 16 + wn * FN) * p.k32 * 64 + lane) * 8;
+  const bf16_t* wfp = p.wfrag + (long long)lane * 8;
+  long long wtile[FN];
+#pragma unroll
+  for (int i = 0; i < FN; ++i) wtile[i] = (long long)min(n0 / 16 + wn * FN + i, p.n16 - 1) * p.k32 * 512;
   const int cin32 = p.Cin >> 5;
   bf16x8 wcur[FN], wnxt[FN];
   auto load_w = [&](int kidx, bf16x8 (&dst)[FN]) {
 #pragma unroll
-    for (int i = 0; i < FN; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(wfp + ((long long)i * p.k32 + kidx) * 512);
+    for (int i = 0; i < FN; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(wfp + wtile[i] + (long long)kidx * 512);
   };
 
   load_patch(0);
@@ -605,6 +614,9 @@ static int dispatch(ConvArgs& a, hipStream_t stream, int cfg) {
                  // except on 512->512 (fewer barriers, but 132 VGPRs -> 3 waves/SIMD), so auto never picks it
       if (!a.wfrag) return -14;
       return launch_impl<64, 128, 1, 4, IS_1X1, true, 128>(a, stream);
+    // Bigger tiles (128x128, 256x128, 128x256 with direct weights) were measured and dropped: 1.3x (128x128) to
+    // 4-5x (256-wide) SLOWER than 64x128 on every layer (profiles/06_conv_tile_sweep.txt) - this loop hides
+    // global-load latency with resident blocks per CU, not with software pipelining, and big tiles cut those.
     default: return -4;
   }
 }
@@ -613,10 +625,14 @@ extern "C" int dlamd_conv2d(const void* x, const void* w, const float* bias, con
                             int B, int H, int W, int Cin, int x_cstride, int Cout, int kh, int kw, int sh, int sw,
                             int ph, int pw, int act, int res_mode, int res_cstride, int out_mode, int out_f,
                             int y_cstride, int y_coff, int y_f32, float thr, int cfg, const void* wfrag,
-                            hipStream_t stream) {
+                            int wfrag_n16, int wfrag_k32, hipStream_t stream) {
   ConvArgs a;
   a.wfrag = (const bf16_t*)wfrag;
   a.k32 = (kh * kw * Cin + 127) / 128 * 4;   // weight fragments are zero-padded to a multiple of 128 in K
+  a.n16 = wfrag_n16;
+  // host-side contract for the fragment buffer: the caller states its real extent ([n16][k32][64][8]); the K
+  // extent must be the padded K the kernels step through and the N extent must cover every output channel
+  if (wfrag && (wfrag_k32 != a.k32 || wfrag_n16 < (Cout + 15) / 16)) return -15;
   a.x = (const bf16_t*)x;
   a.w = (const bf16_t*)w;
   a.bias = bias;

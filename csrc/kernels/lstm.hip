@@ -321,6 +321,212 @@ __global__ __launch_bounds__(512) void lstm_bidir_kernel2(const bf16_t* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v3 (W_hh half resident): v2x16 runs at the L2 -> CU bandwidth - every step a workgroup pulls the whole
+// 2*H*4H = 512 KB W_hh slice of its direction through L2 at the ~70 GB/s a CU gets from L2
+// (MI355X_MICROARCH "Indexed rows"), i.e. ~7.5 us per step.  A CU cannot hold 512 KB, but it can hold half:
+//   K-steps 0,1  -> registers   (8 waves x 64 lanes x 64 VGPRs = 128 KB)
+//   K-steps 2,3  -> LDS         (128 KB, read back as conflict-free contiguous ds_read_b128)
+//   K-steps 4..7 -> streamed from L2 as before (256 KB per step), two K-steps in flight
+// The resident K-steps are computed first, so the streamed fragments (issued at the end of the previous
+// step) have the whole gate math + barrier + resident MFMAs to arrive.
+template <int H>
+__global__ __launch_bounds__(512) void lstm_bidir_kernel3(const bf16_t* __restrict__ xproj, const bf16_t* __restrict__ wfrag,
+                                                          const int* __restrict__ lens,
+                                                          const long long* __restrict__ row_off,
+                                                          const int* __restrict__ tcap, const int* __restrict__ perm,
+                                                          bf16_t* __restrict__ y, int N, int T, int ndir) {
+  constexpr int G = 4 * H;
+  constexpr int NW = 8;
+  constexpr int TILES = G / 16 / NW;
+  constexpr int KS = H / 32;
+  constexpr int HROW = H * 2 + 16;
+  constexpr int KR = 2, KL = 2;                 // K-steps resident in registers / in LDS
+  static_assert(KS == 8 && TILES == 8, "H = 256");
+  extern __shared__ __attribute__((aligned(16))) char smem3[];
+  char* hb0 = smem3;
+  char* hb1 = smem3 + 16 * HROW;
+  char* wl = smem3 + 2 * 16 * HROW;             // [wave][KL][TILES][64 lanes] x 16 B
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int seq_l = lane & 15, fq = lane >> 4;
+  const int dir = blockIdx.y;
+  const long long xrow = (long long)ndir * G;
+  const long long yrow = (long long)ndir * H;
+
+  const int slot = blockIdx.x * 16 + seq_l;
+  const bool ok = slot < N;
+  const int n = ok ? (perm ? perm[slot] : slot) : 0;
+  const int cap = ok ? (tcap ? tcap[n] : T) : 0;
+  const int len = ok ? (lens ? min(lens[n], cap) : cap) : 0;
+  const long long row0 = ok ? (row_off ? row_off[n] : (long long)n * T) : 0;
+  const bf16_t* xp = xproj + row0 * xrow + (long long)dir * G + (wave * TILES) * 16 + fq * 4;
+  bf16_t* yp = y + row0 * yrow + (long long)dir * H;
+  int maxlen = len;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
+
+  for (int i = tid; i < 2 * 16 * HROW / 4; i += 512) reinterpret_cast<uint32_t*>(smem3)[i] = 0u;
+
+  const bf16_t* wf = wfrag + (long long)dir * G * H + (long long)wave * TILES * KS * 64 * 8 + lane * 8;
+  // resident fragments
+  bf16x8 wr[KR][TILES];
+#pragma unroll
+  for (int k = 0; k < KR; ++k)
+#pragma unroll
+    for (int i = 0; i < TILES; ++i) wr[k][i] = *reinterpret_cast<const bf16x8*>(wf + (long long)(i * KS + k) * 64 * 8);
+  char* wlw = wl + ((wave * KL * TILES) * 64 + lane) * 16;
+#pragma unroll
+  for (int k = 0; k < KL; ++k)
+#pragma unroll
+    for (int i = 0; i < TILES; ++i)
+      *reinterpret_cast<bf16x8*>(wlw + (k * TILES + i) * 1024) =
+          *reinterpret_cast<const bf16x8*>(wf + (long long)(i * KS + KR + k) * 64 * 8);
+  __syncthreads();
+
+  float cst[TILES];
+#pragma unroll
+  for (int i = 0; i < TILES; ++i) cst[i] = 0.f;
+
+  // streamed fragments: wa holds K-step 4 then 6, wb holds 5 then 7
+  bf16x8 wa[TILES], wb[TILES];
+#pragma unroll
+  for (int i = 0; i < TILES; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(wf + (long long)(i * KS + 4) * 64 * 8);
+#pragma unroll
+  for (int i = 0; i < TILES; ++i) wb[i] = *reinterpret_cast<const bf16x8*>(wf + (long long)(i * KS + 5) * 64 * 8);
+  u32x2 xc[TILES];
+  {
+    const int t0 = dir == 0 ? 0 : (len - 1);
+#pragma unroll
+    for (int i = 0; i < TILES; ++i) {
+      xc[i] = u32x2{0u, 0u};
+      if (len > 0) xc[i] = *reinterpret_cast<const u32x2*>(xp + (long long)t0 * xrow + i * 16);
+    }
+  }
+
+  for (int step = 0; step < maxlen; ++step) {
+    const char* hc = ((step & 1) ? hb1 : hb0) + seq_l * HROW + fq * 16;
+    char* hn = (step & 1) ? hb0 : hb1;
+    const bf16_t* wfs = wf;          // keep the streamed W loads inside the step loop (see v1)
+    asm volatile("" : "+v"(wfs));
+    const bool act = step < len;
+    const int tt = dir == 0 ? step : (len - 1 - step);
+    f32x4 acc[TILES];
+#pragma unroll
+    for (int i = 0; i < TILES; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- resident K-steps: registers
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hc + k * 64);
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[k][i], hf, acc[i], 0, 0, 0);
+    }
+    // ---- resident K-steps: LDS
+#pragma unroll
+    for (int k = 0; k < KL; ++k) {
+      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hc + (KR + k) * 64);
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) {
+        const bf16x8 w = *reinterpret_cast<const bf16x8*>(wlw + (k * TILES + i) * 1024);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, hf, acc[i], 0, 0, 0);
+      }
+    }
+    // ---- streamed K-steps 4..7
+    {
+      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hc + 4 * 64);
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[i], hf, acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(wfs + (long long)(i * KS + 6) * 64 * 8);
+    }
+    {
+      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hc + 5 * 64);
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[i], hf, acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) wb[i] = *reinterpret_cast<const bf16x8*>(wfs + (long long)(i * KS + 7) * 64 * 8);
+    }
+    {
+      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hc + 6 * 64);
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[i], hf, acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(wfs + (long long)(i * KS + 4) * 64 * 8);
+    }
+    {
+      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hc + 7 * 64);
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[i], hf, acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) wb[i] = *reinterpret_cast<const bf16x8*>(wfs + (long long)(i * KS + 5) * 64 * 8);
+    }
+    // ---- gates
+    const char* hcr = ((step & 1) ? hb1 : hb0);
+#pragma unroll
+    for (int a = 0; a < TILES / 4; ++a) {
+      bf16x4 hv;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = a * 4 + q;
+        const u32x2 raw = xc[i];
+        float ig = dl_sigmoid(acc[i][0] + bf16_bits_to_f32(raw[0] & 0xffffu));
+        float fg = dl_sigmoid(acc[i][1] + bf16_bits_to_f32(raw[0] >> 16));
+        float gg = dl_tanh(acc[i][2] + bf16_bits_to_f32(raw[1] & 0xffffu));
+        float og = dl_sigmoid(acc[i][3] + bf16_bits_to_f32(raw[1] >> 16));
+        float c = fg * cst[i] + ig * gg;
+        float h = og * dl_tanh(c);
+        if (act) cst[i] = c;
+        hv[q] = (bf16_t)h;
+      }
+      const int unit = (wave * (TILES / 4) + a) * 16 + fq * 4;
+      const int hoff = seq_l * HROW + unit * 2;
+      if (act) {
+        *reinterpret_cast<bf16x4*>(hn + hoff) = hv;
+        *reinterpret_cast<bf16x4*>(yp + (long long)tt * yrow + unit) = hv;
+      } else {
+        *reinterpret_cast<u32x2*>(hn + hoff) = *reinterpret_cast<const u32x2*>(hcr + hoff);
+      }
+    }
+    {
+      // next step's pre-activations (HBM), straight into xc now that the gates have consumed it: the load has
+      // the whole MFMA phase of the next step to land, and sits behind every W load that step waits on first
+      const bool nact = step + 1 < len;
+      const int tn = dir == 0 ? step + 1 : (len - 2 - step);
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) {
+        xc[i] = u32x2{0u, 0u};
+        if (nact) xc[i] = *reinterpret_cast<const u32x2*>(xp + (long long)tn * xrow + i * 16);
+      }
+    }
+    __syncthreads();
+  }
+  if (ok) {
+    for (int t = len; t < cap; ++t)
+#pragma unroll
+      for (int a = 0; a < TILES / 4; ++a) {
+        const int unit = (wave * (TILES / 4) + a) * 16 + fq * 4;
+        *reinterpret_cast<u32x2*>(yp + (long long)t * yrow + unit) = u32x2{0u, 0u};
+      }
+  }
+}
+
+static int launch_lstm3(const void* xproj, const void* wfrag, const void* lens, const void* row_off, const void* tcap,
+                        const void* perm, void* y, int N, int T, int ndir, hipStream_t stream) {
+  constexpr int H = 256;
+  const size_t smem = 2 * 16 * (H * 2 + 16) + 8 * 2 * 8 * 1024;      // h double buffer + 128 KB of W_hh
+  auto k = lstm_bidir_kernel3<H>;
+  static bool set = false;
+  if (!set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return -5;
+    set = true;
+  }
+  dim3 grid((N + 15) / 16, ndir);
+  hipLaunchKernelGGL(k, grid, dim3(512), smem, stream, (const bf16_t*)xproj, (const bf16_t*)wfrag, (const int*)lens,
+                     (const long long*)row_off, (const int*)tcap, (const int*)perm, (bf16_t*)y, N, T, ndir);
+  return DLAMD_CHECK_LAUNCH();
+}
+
 template <int H, int ST>
 static int launch_lstm2(const void* xproj, const void* wfrag, const void* lens, const void* row_off, const void* tcap,
                         const void* perm, void* y, int N, int T, int ndir, hipStream_t stream) {
@@ -338,11 +544,13 @@ static int launch_lstm2(const void* xproj, const void* wfrag, const void* lens, 
 
 // xproj: [N, T, ndir*4H] bf16 with gate columns in the permuted order (see
 // ops/lstm.py: lstm_gate_permutation); wfrag: fragment-ordered W_hh per direction.
+static int g_variant = -1;
 static int variant_env() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("DLAMD_LSTM_VARIANT"); v = e ? atoi(e) : 0; }
-  return v;
+  if (g_variant < 0) { const char* e = getenv("DLAMD_LSTM_VARIANT"); g_variant = e ? atoi(e) : 0; }
+  return g_variant;
 }
+// tests / benchmarks: force a kernel variant (0 = automatic)
+extern "C" void dlamd_lstm_set_variant(int v) { g_variant = v < 0 ? 0 : v; }
 
 // Ragged mode: row_off / tcap (and optionally perm) describe sequences packed back to back as rows of xproj / y.
 extern "C" int dlamd_lstm_bidir(const void* xproj, const void* wfrag, const void* lens, const void* row_off,
@@ -358,6 +566,10 @@ extern "C" int dlamd_lstm_bidir(const void* xproj, const void* wfrag, const void
   // Measured on MI355X (us per step, H=256, both directions): N=970: v1 10.5, v2x16 7.5, v2x32 10.0;
   // N=4000: v2x16 16.4, v2x32 13.1 -> 8-wave kernel everywhere, 32 sequences once CUs are oversubscribed.
   const int var = variant_env();
+  // v3 (half of W_hh resident in registers + LDS) beats both v2 shapes at every batch size measured:
+  // N=1075: 4.94 us/step vs 7.23 (v2x16); N=4000: 10.0 vs 12.65 (v2x32)  [bench/lstm_bench.py]
+  if (H == 256 && (var == 4 || (var == 0 && N >= 64)))
+    return launch_lstm3(xproj, wfrag, lens, row_off, tcap, perm, y, N, T, ndir, stream);
   if (H == 256 && (var == 3 || (var == 0 && N >= 3072)))
     return launch_lstm2<256, 2>(xproj, wfrag, lens, row_off, tcap, perm, y, N, T, ndir, stream);
   if (H == 256 && (var == 2 || (var == 0 && N >= 64)))

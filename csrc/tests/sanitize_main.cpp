@@ -1,0 +1,218 @@
+// Host-code sanitizer harness: the native PDF reader, JPEG scanner, dynamic batcher and BPE
+// vocabulary compiled with -fsanitize=address,undefined and driven with (a) well-formed documents given on the
+// command line and (b) thousands of mutated / truncated copies of them.  Any heap overflow, use-after-free,
+// signed overflow or misaligned access aborts the run; malformed input must only ever produce error codes.
+//
+//   python -m distributed_llms_amd.utils.sanitize            (builds build/sanitize/dlamd_san and runs it)
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+extern "C" {
+struct DlpdfPageInfo {
+  double width_pt, height_pt;
+  int32_t rotate, n_images;
+  int64_t chars_visible, chars_invisible, unmapped, decoded;
+  double image_coverage;
+  int32_t has_error, pad;
+};
+struct DlpdfImageInfo {
+  int32_t obj_num, width, height, bpc, ncomp, codec, out_channels, pad;
+  int64_t stream_off, stream_len;
+  double x0, y0, x1, y1;
+};
+struct DlpdfClassify {
+  int32_t n_pages, is_text;
+  int32_t pages_with_text, pages_image_dominant;
+  double avg_chars, garbled_ratio, avg_coverage;
+};
+void* dlpdf_open(const uint8_t* data, size_t n, char* err, int errlen);
+void dlpdf_close(void* h);
+int dlpdf_page_count(void* h);
+int dlpdf_page_info(void* h, int page, DlpdfPageInfo* out);
+int dlpdf_page_text(void* h, int page, int include_invisible, const char** out, size_t* len);
+int dlpdf_image_info(void* h, int page, int idx, DlpdfImageInfo* out);
+int dlpdf_image_jpeg_bytes(void* h, int page, int idx, uint8_t** out, size_t* len);
+void dlpdf_free(void* p);
+long long dlpdf_image_decode(void* h, int page, int idx, uint8_t* dst, size_t dst_len);
+int dlpdf_classify(void* h, DlpdfClassify* out);
+int dljpeg_sizes(int* info_size, int* tables_size);
+int dljpeg_scan(const uint8_t* d, size_t n, void* info, void* tables, uint32_t* seg_offsets, int max_segs);
+
+void* dlrt_batcher_create(uint64_t budget, int max_items, int64_t max_wait_us);
+void dlrt_batcher_destroy(void* h);
+int dlrt_batcher_push(void* h, uint64_t key, uint64_t id, uint64_t cost);
+void dlrt_batcher_close(void* h);
+int dlrt_batcher_pop(void* h, int flush, int64_t timeout_us, uint64_t* ids, int cap, uint64_t* key_out);
+int dlrt_batcher_pending(void* h);
+
+void* dlbpe_create_bytes();
+void* dlbpe_create(const char* vocab_json, long long n, const char* merges_txt, long long m);
+void dlbpe_destroy(void* h);
+long long dlbpe_decode_batch(void* h, const int32_t* ids, int rows, int cols, int stop_at_eos, char* out, long long cap,
+                             long long* offsets);
+long long dlbpe_encode(void* h, const char* utf8, long long n, int32_t* out_ids, long long cap);
+}
+
+static std::vector<uint8_t> read_file(const char* path) {
+  std::vector<uint8_t> v;
+  FILE* f = fopen(path, "rb");
+  if (!f) return v;
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  v.resize(n > 0 ? (size_t)n : 0);
+  if (n > 0 && fread(v.data(), 1, (size_t)n, f) != (size_t)n) v.clear();
+  fclose(f);
+  return v;
+}
+
+// Walks everything the Python binding can reach. Returns pages seen (0 when the open was refused).
+static int walk(const std::vector<uint8_t>& pdf, long long* chars, int* images) {
+  char err[256] = {0};
+  void* h = dlpdf_open(pdf.data(), pdf.size(), err, sizeof err);
+  if (!h) return 0;
+  const int n = dlpdf_page_count(h);
+  int isz = 0, tsz = 0;
+  dljpeg_sizes(&isz, &tsz);
+  std::vector<uint8_t> jinfo(isz), jtab(tsz);
+  for (int p = 0; p < n && p < 64; ++p) {
+    DlpdfPageInfo pi;
+    if (dlpdf_page_info(h, p, &pi) != 0) continue;
+    const char* t = nullptr;
+    size_t tl = 0;
+    if (dlpdf_page_text(h, p, 1, &t, &tl) == 0) {
+      unsigned acc = 0;
+      for (size_t i = 0; i < tl; ++i) acc += (unsigned char)t[i];   // touch every byte
+      *chars += (long long)tl + (acc & 0);
+    }
+    for (int k = 0; k < pi.n_images && k < 16; ++k) {
+      DlpdfImageInfo ii;
+      if (dlpdf_image_info(h, p, k, &ii) != 0) continue;
+      ++*images;
+      if (ii.codec == 1) {
+        uint8_t* jb = nullptr;
+        size_t jl = 0;
+        if (dlpdf_image_jpeg_bytes(h, p, k, &jb, &jl) == 0 && jb) {
+          std::vector<uint32_t> segs(4096);
+          dljpeg_scan(jb, jl, jinfo.data(), jtab.data(), segs.data(), (int)segs.size());
+          dlpdf_free(jb);
+        }
+      } else if (ii.codec == 0 && ii.width > 0 && ii.height > 0 && (long long)ii.width * ii.height < (1LL << 26)) {
+        std::vector<uint8_t> dst((size_t)ii.width * ii.height * (ii.out_channels > 0 ? ii.out_channels : 1));
+        dlpdf_image_decode(h, p, k, dst.data(), dst.size());
+        if (dst.size() > 8) dlpdf_image_decode(h, p, k, dst.data(), dst.size() / 2);   // short buffer must be refused
+      }
+    }
+  }
+  DlpdfClassify c;
+  dlpdf_classify(h, &c);
+  dlpdf_close(h);
+  return n;
+}
+
+static void fuzz_pdf(const std::vector<uint8_t>& seed, int iters, uint32_t rng_seed) {
+  std::mt19937 rng(rng_seed);
+  long long chars = 0;
+  int images = 0, opened = 0;
+  for (int it = 0; it < iters; ++it) {
+    std::vector<uint8_t> m = seed;
+    const int mode = (int)(rng() % 5);
+    if (mode == 0 && m.size() > 16) m.resize(rng() % m.size());                       // truncate
+    else if (mode == 1) for (int k = 0; k < 1 + (int)(rng() % 8); ++k) m[rng() % m.size()] = (uint8_t)rng();   // byte flips
+    else if (mode == 2 && m.size() > 64) {                                              // splice a window
+      size_t a = rng() % m.size(), b = rng() % m.size(), l = rng() % 64;
+      for (size_t k = 0; k < l && a + k < m.size() && b + k < m.size(); ++k) m[a + k] = m[b + k];
+    } else if (mode == 3) {                                                             // digit corruption (lengths, offsets, refs)
+      for (int k = 0; k < 6; ++k) { size_t p = rng() % m.size(); if (m[p] >= '0' && m[p] <= '9') m[p] = '0' + rng() % 10; }
+    } else if (m.size() > 32) {                                                         // drop a slice
+      size_t a = rng() % m.size(), l = 1 + rng() % 32;
+      m.erase(m.begin() + a, m.begin() + std::min(m.size(), a + l));
+    }
+    opened += walk(m, &chars, &images) > 0;
+  }
+  printf("  fuzz: %d variants, %d still opened, %lld text bytes, %d images walked\n", iters, opened, chars, images);
+}
+
+static void batcher_stress() {
+  void* b = dlrt_batcher_create(1 << 20, 8, 2000);
+  std::atomic<long long> popped{0};
+  std::atomic<bool> closed{false};
+  std::vector<std::thread> th;
+  for (int p = 0; p < 4; ++p)
+    th.emplace_back([b, p] { for (int i = 0; i < 5000; ++i) dlrt_batcher_push(b, (uint64_t)(i % 5), (uint64_t)(p * 100000 + i + 1), 1000 + i % 7); });
+  for (int c = 0; c < 2; ++c)
+    th.emplace_back([b, &popped, &closed] {
+      uint64_t ids[8], key;
+      for (;;) {
+        const bool was_closed = closed.load();
+        const int n = dlrt_batcher_pop(b, 0, 5000, ids, 8, &key);   // 0 = timeout, or closed and drained
+        popped += n;
+        if (n == 0 && was_closed) break;
+      }
+    });
+  for (int p = 0; p < 4; ++p) th[p].join();
+  while (dlrt_batcher_pending(b) > 0) std::this_thread::sleep_for(std::chrono::milliseconds(2));
+  dlrt_batcher_close(b);
+  closed.store(true);
+  for (size_t i = 4; i < th.size(); ++i) th[i].join();
+  dlrt_batcher_destroy(b);
+  printf("  batcher: 20000 pushed, %lld popped\n", popped.load());
+  if (popped.load() != 20000) { fprintf(stderr, "batcher lost items\n"); exit(3); }
+}
+
+static void bpe_stress() {
+  void* v = dlbpe_create_bytes();
+  std::mt19937 rng(7);
+  for (int it = 0; it < 2000; ++it) {
+    std::string s(rng() % 200, 0);
+    for (auto& c : s) c = (char)rng();
+    std::vector<int32_t> ids(s.size() + 4);
+    long long n = dlbpe_encode(v, s.data(), (long long)s.size(), ids.data(), (long long)ids.size());
+    std::vector<char> out(s.size() + 8);
+    long long off[2];
+    long long m = dlbpe_decode_batch(v, ids.data(), 1, (int)n, 1, out.data(), (long long)out.size(), off);
+    if (n != (long long)s.size() || m != n || memcmp(out.data(), s.data(), s.size()) != 0) { fprintf(stderr, "bpe roundtrip\n"); exit(4); }
+    for (auto& i : ids) i = (int32_t)rng();                               // wild ids, tiny output buffer
+    dlbpe_decode_batch(v, ids.data(), 1, (int)ids.size(), 0, out.data(), 3, off);
+  }
+  dlbpe_destroy(v);
+  const std::string good = "{\"<s>\":0,\"</s>\":1,\"a\":2,\"\\u0120\":3,\"\\u0120a\":4,\"\\ud83d\\ude00\":5}";
+  for (int it = 0; it < 4000; ++it) {
+    std::string j = good;
+    for (int k = 0; k < (int)(rng() % 4); ++k) j[rng() % j.size()] = (char)rng();
+    if (rng() % 3 == 0) j.resize(rng() % j.size());
+    void* h = dlbpe_create(j.data(), (long long)j.size(), "\xc4\xa0 a\n", 5);
+    if (h) {
+      int32_t ids[16];
+      dlbpe_encode(h, "a a  a", 6, ids, 16);
+      dlbpe_destroy(h);
+    }
+  }
+  printf("  bpe: round trips and malformed vocabularies ok\n");
+}
+
+int main(int argc, char** argv) {
+  int iters = 1500;
+  for (int i = 1; i < argc; ++i) {
+    if (!strncmp(argv[i], "--iters=", 8)) { iters = atoi(argv[i] + 8); continue; }
+    std::vector<uint8_t> pdf = read_file(argv[i]);
+    if (pdf.empty()) { fprintf(stderr, "cannot read %s\n", argv[i]); return 2; }
+    long long chars = 0;
+    int images = 0;
+    const int n = walk(pdf, &chars, &images);
+    printf("%s: %d pages, %lld text bytes, %d images\n", argv[i], n, chars, images);
+    if (n <= 0) { fprintf(stderr, "well-formed seed did not open\n"); return 2; }
+    fuzz_pdf(pdf, iters, 1234u + (uint32_t)i);
+  }
+  batcher_stress();
+  bpe_stress();
+  printf("sanitize: OK\n");
+  return 0;
+}

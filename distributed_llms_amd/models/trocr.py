@@ -266,18 +266,16 @@ class TrOCR(nn.Module):
             psum += st.probs
         return out[:, :B].t().contiguous(), (psum[:B] / max_len)
 
-    def tokens_to_text(self, tokens: torch.Tensor) -> List[str]:
-        """Byte-level vocabulary: ids 0..3 are specials (bos, pad, eos, unk), 4..259 are the raw bytes."""
-        out = []
-        for row in tokens.cpu().tolist():
-            bs = bytearray()
-            for t in row:
-                if t == self.cfg.eos:
-                    break
-                if 4 <= t < 260:
-                    bs.append(t - 4)
-            out.append(bs.decode("utf-8", "replace"))
-        return out
+    def tokens_to_text(self, tokens: torch.Tensor, vocab=None) -> List[str]:
+        """ids -> text through the native byte-level vocabulary (csrc/runtime/bpe_tokenizer.cpp).  Without a
+        loaded vocab.json the built-in one is used: ids 0..3 are specials (bos, pad, eos, unk), 4..259 the raw bytes."""
+        from ..runtime.tokenizer import ByteLevelVocab
+
+        if vocab is None:
+            vocab = getattr(self, "_vocab", None)
+            if vocab is None:
+                vocab = self._vocab = ByteLevelVocab()
+        return vocab.decode_batch(tokens.detach().cpu().numpy(), stop_at_eos=True)
 
     def flops_per_crop(self, decode_tokens: int) -> float:
         cfg = self.cfg

@@ -77,12 +77,15 @@ def _declare(l: ctypes.CDLL) -> None:
             fn.argtypes = args
             fn.restype = ctypes.c_int
 
-    sig("dlamd_conv2d", [vp, vp, vp, vp, vp, vp] + [i] * 20 + [f, i, vp, vp])
+    sig("dlamd_conv2d", [vp, vp, vp, vp, vp, vp] + [i] * 20 + [f, i, vp, i, i, vp])
     sig("dlamd_resample", [vp, i, vp, i, i, f, f, f, f, f, f, vp])
     sig("dlamd_db_postprocess", [vp] * 10 + [i, i, i, i, i, f, f, i, vp])
     sig("dlamd_row_argmax", [vp, i, vp, vp, ll, i, ll, vp])
     sig("dlamd_ctc_collapse", [vp, vp, vp, vp, vp, vp, vp, i, i, i, vp])
     sig("dlamd_lstm_bidir", [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, vp])
+    if hasattr(l, "dlamd_lstm_set_variant"):
+        l.dlamd_lstm_set_variant.argtypes = [i]
+        l.dlamd_lstm_set_variant.restype = None
     sig("dlamd_layernorm", [vp, vp, vp, vp, vp, ll, i, f, i, vp])
     sig("dlamd_attention_fwd", [vp, vp, vp, vp, i, i, i, i, ll, ll, ll, ll, ll, ll, ll, ll, f, i, vp])
     sig("dlamd_attention_decode", [vp, ll, vp, vp, ll, ll, vp, vp, ll, vp, i, i, vp, ll, i, i, f, vp])

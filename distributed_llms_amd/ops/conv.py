@@ -199,13 +199,17 @@ def conv2d_nhwc(
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() >= Cout and bias.is_contiguous()
 
+    frag = None
+    if USE_WEIGHT_FRAGMENTS:
+        frag = wfrag if wfrag is not None else weight_fragments(w)
+        assert frag.is_contiguous() and frag.dtype == torch.bfloat16 and frag.dim() == 4 and frag.shape[2:] == (64, 8)
     rc = _loader.lib().dlamd_conv2d(
         _loader.ptr(x), _loader.ptr(w), _loader.ptr(bias), _loader.ptr(res if res_mode != RES_NONE else None),
         _loader.ptr(y), _loader.ptr(mask),
         B, H, W, Cin, x_cstride, Cout, kh, kw, sh, sw, ph, pw,
         ACT[act], res_mode, res_cstride, out_mode, out_f, y_cstride, y_coff,
         1 if out_dtype == torch.float32 else 0, float(thr), cfg,
-        _loader.ptr(wfrag if wfrag is not None else weight_fragments(w)) if USE_WEIGHT_FRAGMENTS else None,
+        _loader.ptr(frag), frag.shape[0] if frag is not None else 0, frag.shape[1] if frag is not None else 0,
         _loader.stream_ptr(),
     )
     _loader.check(rc, "dlamd_conv2d")

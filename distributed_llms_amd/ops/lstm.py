@@ -160,3 +160,8 @@ def lstm_layer_ragged(x: torch.Tensor, p: PackedLSTM, lay: RaggedLayout) -> torc
     )
     _loader.check(rc, "dlamd_lstm_bidir")
     return y
+
+
+def set_kernel_variant(variant: int) -> None:
+    """Tests / benchmarks: force a recurrence kernel (0 automatic, 1 v1, 2 v2x16, 3 v2x32, 4 v3 half-resident W_hh)."""
+    _loader.lib().dlamd_lstm_set_variant(int(variant))

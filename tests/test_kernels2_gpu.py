@@ -191,10 +191,14 @@ def test_row_argmax_small_vocab_confidence_is_finite(V):
         assert torch.equal(ids[n, : int(rln[n])].cpu(), rids[n, : int(rln[n])])
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("N", [40, 300])
-def test_lstm_ragged_variants_match_reference(N):
-    """v1 (N < 256) and v2 (N >= 256, 32 sequences per workgroup) on a ragged, length-sorted layout."""
+def test_lstm_ragged_variants_match_reference(N, variant):
+    """Every recurrence kernel (v1, v2 with 16 / 32 sequences per workgroup, v3 with half of W_hh resident in
+    registers + LDS) and the automatic choice, on a ragged, length-sorted layout."""
     from distributed_llms_amd.ops import lstm
+
+    lstm.set_kernel_variant(variant)
 
     g = torch.Generator().manual_seed(N)
     H, I = 256, 64
@@ -211,7 +215,10 @@ def test_lstm_ragged_variants_match_reference(N):
     lay_c = lstm.RaggedLayout(row_off, tcap, lens, perm, R, int(tcap.max()))
     ref = lstm.lstm_layer_ragged(x, p, lay_c).float()
     lay_g = lstm.RaggedLayout(row_off.to(DEV), tcap.to(DEV), lens.to(DEV), perm.to(DEV), R, int(tcap.max()))
-    got = lstm.lstm_layer_ragged(x.to(DEV), p.to(DEV), lay_g).float().cpu()
+    try:
+        got = lstm.lstm_layer_ragged(x.to(DEV), p.to(DEV), lay_g).float().cpu()
+    finally:
+        lstm.set_kernel_variant(0)
     err = (got - ref).abs()
     assert err.max().item() < 0.06 and err.mean().item() < 4e-3, (err.max().item(), err.mean().item())
 
