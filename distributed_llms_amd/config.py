@@ -85,6 +85,15 @@ def _get_bool(env: Mapping[str, str], key: str, default: bool) -> bool:
     return v.strip().lower() in ("1", "true", "yes", "on")
 
 
+def _shipped_weights():
+    """The weights this repository trains on its synthetic page family (train/page_trainer.py) ship under
+    ``<repo>/weights``; they are the default when OCR_WEIGHTS_DIR is unset ("none" forces random init)."""
+    import pathlib
+
+    wd = pathlib.Path(__file__).resolve().parents[1] / "weights"
+    return str(wd) if (wd / "dbnet.safetensors").exists() and (wd / "crnn.safetensors").exists() else None
+
+
 @dataclass
 class Settings:
     # --- reference variables -------------------------------------------------
@@ -141,7 +150,7 @@ class Settings:
             recognizer=e.get("OCR_RECOGNIZER", "crnn"),
             dtype=e.get("OCR_DTYPE", "bf16"),
             rec_height=_get_int(e, "OCR_REC_HEIGHT", 48),
-            weights_dir=e.get("OCR_WEIGHTS_DIR") or None,
+            weights_dir=e.get("OCR_WEIGHTS_DIR") or _shipped_weights(),
             doc_deadline_s=_get_float(e, "OCR_DOC_DEADLINE_S", 600.0),
             hbm_budget_gb=_get_float(e, "OCR_HBM_BUDGET_GB", 200.0),
             use_hip_graphs=_get_bool(e, "OCR_USE_HIP_GRAPHS", True),

@@ -300,7 +300,11 @@ class OcrEngine:
         lens_all = np.maximum((out_w + 3) // 4, 1).astype(np.int32)
         with ctx:
             buckets = [(int(wb), idx_all[bucket[idx_all] == wb]) for wb in np.unique(bucket[idx_all])]
-            small = cfg.use_hip_graphs and idx_all.size <= 2 * cfg.graph_max_crops
+            # The recurrence costs T sequential steps per launch whatever the batch, so width buckets must not
+            # run one after another: a single page spread over 8 buckets spent 49 ms in 16 BiLSTM launches
+            # (profiles/09) against 2 launches in the ragged pass.  Replayed per-bucket graphs are kept for
+            # the one case they win: every crop in a single bucket.
+            small = cfg.use_hip_graphs and len(buckets) == 1 and idx_all.size <= cfg.graph_max_crops
             if self.on_gpu and not small:
                 # throughput regime: every bucket of the batch in ONE ragged recognition pass
                 rb.groups.append(self._rec_gpu_ragged(buckets, boxes, page_of, rot, out_w, lens_all,

@@ -62,7 +62,7 @@ def build_engine(device: str, engine_spec: Dict) -> "object":
     else:
         det, rec = DBNet(), CRNN()
     wd = engine_spec.get("weights_dir")
-    if wd:
+    if wd and str(wd).lower() != "none" and engine_spec.get("model", "full") == "full":
         from ..utils.weights import load_model_weights
 
         load_model_weights(det, os.path.join(wd, "dbnet.safetensors"), strict=False)

@@ -171,7 +171,14 @@ def test_engine_end_to_end_scanned_pdf():
     eng2 = OcrEngine(DEV, cfg=EngineConfig(max_batch_pages=2, det_limit_side=960, use_hip_graphs=False))
     doc3 = DocumentPipeline(eng2, decode_threads=2).process_pdf(pdf, "t", layout_priors=priors)
     assert doc3.text == first
-    assert eng._graphs, "small recognition batches must have gone through hipGraph replay"
+    # crops that all share one width bucket replay a captured graph (several buckets go through the ragged pass:
+    # per-bucket launches would serialise the recurrence); the replay must read what the eager path reads
+    one = [b[:1] for b in priors]
+    g1 = pipe.process_pdf(pdf, "t", layout_priors=one)
+    g2 = pipe.process_pdf(pdf, "t", layout_priors=one)
+    e1 = DocumentPipeline(eng2, decode_threads=2).process_pdf(pdf, "t", layout_priors=one)
+    assert eng._graphs, "single-bucket recognition batches must have gone through hipGraph replay"
+    assert [len(p.lines) for p in g1.pages] == [1, 1, 1] and g1.text == g2.text == e1.text
 
 
 @pytest.mark.parametrize("V", [96, 40, 8])
