@@ -59,6 +59,9 @@ def parse_args():
     ap.add_argument("--stage-times", action="store_true")
     ap.add_argument("--weights", default=str(ROOT / "weights"), help="directory with dbnet/crnn .safetensors")
     ap.add_argument("--random-init", action="store_true", help="ignore trained weights")
+    ap.add_argument("--recognizer", choices=["crnn", "trocr"], default="crnn",
+                    help="trocr: TrOCR-base-sized ViT + decoder (BASELINE config 4; random-init, generator line boxes)")
+    ap.add_argument("--trocr-tokens", type=int, default=32)
     return ap.parse_args()
 
 
@@ -93,6 +96,12 @@ def main():
         rec = CRNN(hidden=64, widths=(16, 32, 32, 32, 64, 64))
         cfg.det_limit_side, cfg.rec_max_width, cfg.rec_width_quantum = 160, 256, 64
         size = (248, 350)
+    if args.recognizer == "trocr" and use_gpu:
+        from distributed_llms_amd.models.trocr import TrOCR
+
+        rec = TrOCR()
+        cfg.trocr_max_tokens = args.trocr_tokens
+        args.random_init = True
     trained = (use_gpu and not args.random_init and os.path.exists(os.path.join(args.weights, "dbnet.safetensors"))
                and os.path.exists(os.path.join(args.weights, "crnn.safetensors")))
     if trained:
@@ -186,7 +195,8 @@ def main():
                       "finds none (detector + post-process still run on every page)" % args.codec))
             if args.input == "pdf" else "synthetic decoded 300-DPI A4 rasters",
             "config": {
-                "model": "DBNet-R18 (1344x960 det input) + CRNN (2xBiLSTM-256, h=48) + CTC greedy",
+                "model": ("DBNet-R18 (1344x960 det input) + CRNN (2xBiLSTM-256, h=48) + CTC greedy" if args.recognizer == "crnn"
+                          else f"DBNet-R18 + TrOCR-base-sized recognizer (ViT-12x768 + decoder-12x1024, {args.trocr_tokens} greedy tokens)"),
                 "global_batch": args.pages_per_doc * world,
                 "seq_len": int(cfg.rec_max_width // 4),
                 "parallelism": f"dp{world}",

@@ -98,6 +98,8 @@ class EngineConfig:
     vertical_ratio: float = 1.5
     use_hip_graphs: bool = True
     graph_max_crops: int = 128
+    trocr_batch: int = 256            # crops per encoder / decoder pass of the transformer recognizer
+    trocr_max_tokens: int = 64        # greedy decode length (the decoder runs a fixed number of steps)
     db: dbpost.DBPostConfig = field(default_factory=dbpost.DBPostConfig)
 
 
@@ -126,7 +128,7 @@ class _RecBatch:
 
 class OcrEngine:
     def __init__(self, device: torch.device | str = "cuda:0", det: Optional[DBNet] = None, rec: Optional[CRNN] = None,
-                 cfg: Optional[EngineConfig] = None, seed: int = 0):
+                 cfg: Optional[EngineConfig] = None, seed: int = 0):   # rec: CRNN or TrOCR
         self.device = torch.device(device)
         self.cfg = cfg or EngineConfig()
         self.on_gpu = self.device.type == "cuda"
@@ -138,13 +140,16 @@ class OcrEngine:
             torch.random.set_rng_state(g)
         self.det = det.to(self.device).prepare()
         self.rec = rec.to(self.device).prepare()
+        # OCR_RECOGNIZER=trocr: ViT encoder + transformer decoder instead of the CRNN
+        self.rec_kind = "crnn" if isinstance(rec, CRNN) else "trocr"
+        self._trocr_event = None      # the decoder's static graph state is shared by both pipeline slots
         self.timer = StageTimer()
         self._ws: Dict[Tuple[int, int, int], dbpost.DBPostWorkspace] = {}
         self._streams = [torch.cuda.Stream(self.device) for _ in range(2)] if self.on_gpu else [None, None]
         self._graphs: Dict[Tuple[int, int, int], "_RecGraph"] = {}
-        cs = self.rec.charset
+        cs = getattr(self.rec, "charset", "")
         self._lut = None
-        if all(ord(c) < 256 for c in cs):
+        if cs and all(ord(c) < 256 for c in cs):
             self._lut = np.frombuffer(("\0" + cs).encode("latin-1"), dtype=np.uint8)
         self.pages_done = 0
         self.lines_done = 0
@@ -298,6 +303,10 @@ class OcrEngine:
         ctx = torch.cuda.stream(db.stream) if self.on_gpu else _null_ctx()
         used_graphs: set = set()
         lens_all = np.maximum((out_w + 3) // 4, 1).astype(np.int32)
+        if self.rec_kind == "trocr":
+            with ctx:
+                self._submit_rec_trocr(rb, db, idx_all, boxes, page_of, rot, (ptrs, Hs, Ws, Cs, Ps))
+            return rb
         with ctx:
             buckets = [(int(wb), idx_all[bucket[idx_all] == wb]) for wb in np.unique(bucket[idx_all])]
             # The recurrence costs T sequential steps per launch whatever the batch, so width buckets must not
@@ -331,7 +340,41 @@ class OcrEngine:
                 rb.event = None
         return rb
 
-    def _crop_items(self, ids, boxes, page_of, rot, out_w, src) -> np.ndarray:
+    def _submit_rec_trocr(self, rb: _RecBatch, db: _DetBatch, idx_all, boxes, page_of, rot, src) -> None:
+        """Transformer recognizer: every line is resized to the encoder's S x S input (as TrOCR does), encoded in
+        batches of ``trocr_batch`` and decoded greedily for ``trocr_max_tokens`` hipGraph-replayed steps."""
+        cfg = self.cfg
+        S = self.rec.cfg.image_size
+        if self.on_gpu and self._trocr_event is not None:
+            db.stream.wait_event(self._trocr_event)          # one decode state: recognition passes run in order
+        for c0 in range(0, idx_all.size, cfg.trocr_batch):
+            ids = idx_all[c0 : c0 + cfg.trocr_batch]
+            if self.on_gpu:
+                items = self._crop_items(ids, boxes, page_of, rot, np.full(boxes.shape[0], S, np.int32), src, out_h=S)
+                host = torch.from_numpy(items.view(np.uint8).reshape(-1)).pin_memory()
+                dev = host.to(self.device, non_blocking=True)
+                x = rs.resample_items_gpu(dev, ids.size, S, S, rs.HALF_MEAN, rs.HALF_STD)
+                rb.keep.append((host, dev))
+            else:
+                regions = [rs.Region(db.srcs[page_of[i]], tuple(float(v) for v in boxes[i]), S, S, int(rot[i])) for i in ids]
+                x = rs.resample_regions(regions, S, S, rs.HALF_MEAN, rs.HALF_STD)
+            toks, conf = self.rec.generate(x, max_len=cfg.trocr_max_tokens, use_graph=cfg.use_hip_graphs)
+            if self.on_gpu:
+                h_tok = torch.empty(toks.shape, dtype=torch.int32, pin_memory=True)
+                h_cf = torch.empty(conf.shape, dtype=torch.float32, pin_memory=True)
+                h_tok.copy_(toks, non_blocking=True)
+                h_cf.copy_(conf, non_blocking=True)
+                rb.groups.append((ids, ("tokens", h_tok, h_cf)))
+            else:
+                rb.groups.append((ids, ("tokens", toks.to(torch.int32), conf.float())))
+        if self.on_gpu:
+            rb.event = torch.cuda.Event()
+            rb.event.record(db.stream)
+            self._trocr_event = rb.event
+        else:
+            rb.event = None
+
+    def _crop_items(self, ids, boxes, page_of, rot, out_w, src, out_h: Optional[int] = None) -> np.ndarray:
         ptrs, Hs, Ws, Cs, Ps = src
         items = np.zeros(ids.size, dtype=rs.ITEM_DTYPE)
         pg = page_of[ids]
@@ -340,7 +383,7 @@ class OcrEngine:
         items["pitch"] = Ps[pg]
         items["x0"], items["y0"] = boxes[ids, 0], boxes[ids, 1]
         items["x1"], items["y1"] = boxes[ids, 2], boxes[ids, 3]
-        items["out_h"], items["out_w"] = self.cfg.rec_height, out_w[ids]
+        items["out_h"], items["out_w"] = (out_h or self.cfg.rec_height), out_w[ids]
         return items
 
     def _rec_gpu_ragged(self, buckets, boxes, page_of, rot, out_w, lens_all, src):
@@ -416,6 +459,13 @@ class OcrEngine:
         texts: List[str] = [""] * n_total
         confs = np.zeros((n_total,), np.float32)
         for ids, out in rb.groups:
+            if isinstance(out[0], str):            # transformer recognizer: token ids -> native BPE decode
+                _, h_tok, h_cf = out
+                strs = self.rec.tokens_to_text(h_tok[: len(ids)])
+                for j, gi in enumerate(ids):
+                    texts[gi] = strs[j]
+                confs[ids] = h_cf[: len(ids)].numpy()
+                continue
             h_ids, h_ln, h_cf = out
             strs = self._strings(h_ids[: len(ids)], h_ln[: len(ids)])
             cf = h_cf[: len(ids)].numpy() if isinstance(h_cf, torch.Tensor) else h_cf

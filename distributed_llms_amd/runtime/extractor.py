@@ -138,18 +138,18 @@ def make_extractor(settings) -> Extractor:
         spec_model = getattr(settings, "cpu_model", "full")
         from .workers import build_engine
 
-        engine = build_engine("cpu", {"model": spec_model, "cfg": cfg, "weights_dir": settings.weights_dir})
+        engine = build_engine("cpu", {"model": spec_model, "cfg": cfg, "weights_dir": settings.weights_dir, "recognizer": settings.recognizer})
         return InlineExtractor(DocumentPipeline(engine))
     if want == 1 and not getattr(settings, "force_pool", False):
         from .workers import build_engine
 
-        engine = build_engine("cuda:0", {"model": "full", "cfg": cfg, "weights_dir": settings.weights_dir})
+        engine = build_engine("cuda:0", {"model": "full", "cfg": cfg, "weights_dir": settings.weights_dir, "recognizer": settings.recognizer})
         engine.warmup(batch=min(4, settings.max_batch_pages))
         return InlineExtractor(DocumentPipeline(engine))
     from .workers import WorkerPool
 
     pool = WorkerPool([f"cuda:{i}" for i in range(min(want, ngpu_visible))],
-                      {"model": "full", "cfg": cfg, "weights_dir": settings.weights_dir},
+                      {"model": "full", "cfg": cfg, "weights_dir": settings.weights_dir, "recognizer": settings.recognizer},
                       fault_inject=settings.fault_inject, max_wait_ms=settings.max_wait_ms,
                       hbm_budget_gb=settings.hbm_budget_gb, doc_deadline_s=settings.doc_deadline_s).start()
     return PoolExtractor(pool)

@@ -47,7 +47,8 @@ def _parse_faults(spec: str) -> Dict[str, float]:
 
 
 def build_engine(device: str, engine_spec: Dict) -> "object":
-    """Construct the per-worker OCR engine.  ``engine_spec``: {'model': 'full'|'tiny', 'cfg': {...}, 'weights_dir': ...}."""
+    """Construct the per-worker OCR engine.
+    ``engine_spec``: {'model': 'full'|'tiny', 'recognizer': 'crnn'|'trocr', 'cfg': {...}, 'weights_dir': ...}."""
     import torch
 
     from ..models.crnn import CRNN
@@ -61,12 +62,21 @@ def build_engine(device: str, engine_spec: Dict) -> "object":
         rec = CRNN(hidden=64, widths=(16, 32, 32, 32, 64, 64))
     else:
         det, rec = DBNet(), CRNN()
+    kind = engine_spec.get("recognizer", "crnn")
+    if kind == "trocr":
+        from ..models.trocr import TrOCR, TrOCRConfig
+
+        tiny = engine_spec.get("model", "full") == "tiny"
+        rec = TrOCR(TrOCRConfig(image_size=64, enc_dim=128, enc_layers=1, enc_heads=2, enc_mlp=256, dec_dim=128, dec_layers=1,
+                                dec_heads=2, dec_ffn=256, vocab=272, max_len=16) if tiny else None)
     wd = engine_spec.get("weights_dir")
     if wd and str(wd).lower() != "none" and engine_spec.get("model", "full") == "full":
         from ..utils.weights import load_model_weights
 
         load_model_weights(det, os.path.join(wd, "dbnet.safetensors"), strict=False)
-        load_model_weights(rec, os.path.join(wd, "crnn.safetensors"), strict=False)
+        rec_file = os.path.join(wd, "trocr.safetensors" if kind == "trocr" else "crnn.safetensors")
+        if kind != "trocr" or os.path.exists(rec_file):
+            load_model_weights(rec, rec_file, strict=False)
     return OcrEngine(device, det, rec, cfg)
 
 

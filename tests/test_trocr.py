@@ -137,3 +137,55 @@ def test_layernorm_decode_attention_and_embedding_kernels():
     ref = T.embed_rows(ids, tok, pos, t3)
     got = T.embed_rows(ids.cuda(), tok.cuda(), pos.cuda(), t3.cuda())
     assert (got.float().cpu() - ref.float()).abs().max().item() < 0.02
+
+
+def _engine_pages(n=3):
+    import torch
+    from distributed_llms_amd.pdf import synth
+    from distributed_llms_amd.runtime.engine import PageImage
+
+    pages = []
+    for s in range(n):
+        pg, tr = synth.render_page(s, size=(248, 350), font_px=10, margin=16)
+        pages.append(PageImage(torch.from_numpy(pg), "d", s, layout_prior=tr.boxes))
+    return pages
+
+
+def test_engine_runs_with_the_transformer_recognizer_cpu():
+    """OCR_RECOGNIZER=trocr: the engine crops to S x S, runs encoder + greedy decoder, decodes tokens
+    with the native byte-level vocabulary, and is deterministic."""
+    from distributed_llms_amd.runtime.workers import build_engine
+
+    eng = build_engine("cpu", {"model": "tiny", "recognizer": "trocr",
+                               "cfg": dict(det_limit_side=160, max_batch_pages=2, trocr_max_tokens=6, trocr_batch=8)})
+    assert eng.rec_kind == "trocr"
+    pages = _engine_pages()
+    a = eng.process_pages(pages)
+    b = eng.process_pages(pages)
+    assert [len(r.lines) for r in a] == [len(p.layout_prior) for p in pages]
+    assert [l.text for r in a for l in r.lines] == [l.text for r in b for l in r.lines]
+    assert all(0.0 <= l.confidence <= 1.0 for r in a for l in r.lines)
+
+
+@pytest.mark.gpu
+def test_engine_transformer_recognizer_gpu_matches_eager_decode():
+    """Same pages through the GPU engine: hipGraph-replayed decode steps, two pipeline slots sharing one decode
+    state (ordered by an event), against the same engine without graphs."""
+    import torch
+    from distributed_llms_amd.models.dbnet import DBNet
+    from distributed_llms_amd.runtime.engine import EngineConfig, OcrEngine
+
+    torch.manual_seed(3)
+    det = DBNet(widths=(16, 32, 32, 64), stem=8, inner=32)
+    rec = TrOCR(SMALL)
+    pages = _engine_pages(5)
+    outs = []
+    for graphs in (True, False):
+        eng = OcrEngine("cuda:0", det, rec, EngineConfig(det_limit_side=160, max_batch_pages=2, trocr_max_tokens=8,
+                                                         trocr_batch=16, use_hip_graphs=graphs))
+        r1 = eng.process_pages(pages)
+        r2 = eng.process_pages(pages)
+        assert [l.text for r in r1 for l in r.lines] == [l.text for r in r2 for l in r.lines]
+        outs.append([l.text for r in r1 for l in r.lines])
+        assert [len(r.lines) for r in r1] == [len(p.layout_prior) for p in pages]
+    assert outs[0] == outs[1]
