@@ -51,6 +51,10 @@ def make_stores(settings: Settings):
         return MemoryStatusStore(ttl=settings.status_ttl), MemoryResultStore()
     client = RespClient(settings.redis_host, settings.redis_port, settings.redis_password)
     status = RedisStatusStore(client, ttl=settings.status_ttl)
+    if settings.resolved_store() == "redis+file":
+        from ..store.results import FileResultStore
+
+        return status, FileResultStore(os.path.join(settings.output_dir, "results"))
     results = MongoResultStore(settings.mongo_connection_string, settings.mongo_db_name,
                                settings.mongo_collection_name, tls=settings.mongo_tls)
     return status, results
@@ -239,11 +243,12 @@ def create_app(settings: Optional[Settings] = None, status: Optional[StatusStore
         elif any(v == "unhealthy" for v in deps):
             status["status"] = "unhealthy"
             _count("health", 503)
-            return JSONResponse(status, status_code=503)
+            return JSONResponse(status, status_code=503, headers={"x-ocr-frontend": settings.node_id})
         else:
             status["status"] = "degraded"
         _count("health", 200)
-        return status
+        # the body is the reference's (ocr_service.py:565-606); which front-end process answered goes in a header
+        return JSONResponse(status, headers={"x-ocr-frontend": settings.node_id})
 
     # ------------------------------------------------------------------ GET /metrics
     @app.get("/metrics")

@@ -105,12 +105,13 @@ class Settings:
     redis_password: Optional[str] = None
     port: int = 8000
     # --- store selection ------------------------------------------------------
-    store: str = "auto"              # auto | redis+mongo | memory
+    store: str = "auto"              # auto | redis+mongo | redis+file | memory
     mongo_tls: Optional[bool] = None  # None -> TLS iff mongodb+srv:// (Atlas), as the reference always used TLS
     status_ttl: int = STATUS_TTL_SECONDS
     output_dir: str = "output"
     # --- engine -----------------------------------------------------------------
     num_gpus: int = -1               # -1: all visible; 0: CPU engine
+    gpu_ids: Optional[str] = None    # "2,3": the devices this process drives (multi-front-end deployments)
     max_batch_pages: int = 32
     max_wait_ms: float = 20.0
     det_limit_side: int = 1344
@@ -144,6 +145,7 @@ class Settings:
             status_ttl=_get_int(e, "OCR_STATUS_TTL", STATUS_TTL_SECONDS),
             output_dir=e.get("OCR_OUTPUT_DIR", "output"),
             num_gpus=_get_int(e, "OCR_NUM_GPUS", -1),
+            gpu_ids=e.get("OCR_GPU_IDS") or None,
             max_batch_pages=_get_int(e, "OCR_MAX_BATCH_PAGES", 32),
             max_wait_ms=_get_float(e, "OCR_MAX_WAIT_MS", 20.0),
             det_limit_side=_get_int(e, "OCR_DET_LIMIT_SIDE", 1344),
@@ -157,13 +159,14 @@ class Settings:
             fault_inject=e.get("FAULT_INJECT", ""),
             force_pool=_get_bool(e, "OCR_FORCE_POOL", False),
             cpu_model=e.get("OCR_CPU_MODEL", "full"),
+            **({"node_id": e["OCR_NODE_ID"]} if e.get("OCR_NODE_ID") else {}),
         )
         s.validate()
         return s
 
     def validate(self) -> None:
-        if self.store not in ("auto", "redis+mongo", "memory"):
-            raise ValueError(f"OCR_STORE must be auto|redis+mongo|memory, got {self.store!r}")
+        if self.store not in ("auto", "redis+mongo", "redis+file", "memory"):
+            raise ValueError(f"OCR_STORE must be auto|redis+mongo|redis+file|memory, got {self.store!r}")
         if self.recognizer not in ("crnn", "trocr"):
             raise ValueError(f"OCR_RECOGNIZER must be crnn|trocr, got {self.recognizer!r}")
         if self.dtype not in ("bf16",):

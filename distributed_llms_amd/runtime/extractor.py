@@ -131,6 +131,11 @@ def make_extractor(settings) -> Extractor:
 
     ngpu_visible = torch.cuda.device_count()
     want = settings.num_gpus if settings.num_gpus >= 0 else ngpu_visible
+    ids = list(range(ngpu_visible))
+    if getattr(settings, "gpu_ids", None):      # OCR_GPU_IDS: the subset of devices this front end drives
+        ids = [int(t) for t in str(settings.gpu_ids).split(",") if t.strip() != "" and int(t) < ngpu_visible]
+        if settings.num_gpus != 0:
+            want = min(want, len(ids)) if settings.num_gpus > 0 else len(ids)
     cfg = dict(det_limit_side=settings.det_limit_side, rec_height=settings.rec_height,
                max_batch_pages=settings.max_batch_pages, use_hip_graphs=settings.use_hip_graphs)
     if want <= 0 or ngpu_visible == 0:
@@ -143,12 +148,12 @@ def make_extractor(settings) -> Extractor:
     if want == 1 and not getattr(settings, "force_pool", False):
         from .workers import build_engine
 
-        engine = build_engine("cuda:0", {"model": "full", "cfg": cfg, "weights_dir": settings.weights_dir, "recognizer": settings.recognizer})
+        engine = build_engine(f"cuda:{ids[0]}", {"model": "full", "cfg": cfg, "weights_dir": settings.weights_dir, "recognizer": settings.recognizer})
         engine.warmup(batch=min(4, settings.max_batch_pages))
         return InlineExtractor(DocumentPipeline(engine))
     from .workers import WorkerPool
 
-    pool = WorkerPool([f"cuda:{i}" for i in range(min(want, ngpu_visible))],
+    pool = WorkerPool([f"cuda:{i}" for i in ids[: min(want, len(ids))]],
                       {"model": "full", "cfg": cfg, "weights_dir": settings.weights_dir, "recognizer": settings.recognizer},
                       fault_inject=settings.fault_inject, max_wait_ms=settings.max_wait_ms,
                       hbm_budget_gb=settings.hbm_budget_gb, doc_deadline_s=settings.doc_deadline_s).start()

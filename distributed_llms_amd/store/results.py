@@ -92,6 +92,55 @@ class MemoryResultStore(ResultStore):
         return len(self._docs)
 
 
+class FileResultStore(ResultStore):
+    """Result rows as one JSON file each under ``<dir>/<sha1(document_id)>.json`` (atomic rename).
+
+    For a single node with several front-end processes and no MongoDB (``OCR_STORE=redis+file``): every
+    process sees every row through the shared directory.  Same row schema as Mongo (2B-8); ``processed_at`` is
+    stored as an ISO string and handed back as ``datetime``."""
+
+    def __init__(self, directory: str):
+        self.dir = directory
+
+    def connect(self) -> None:
+        os.makedirs(self.dir, exist_ok=True)
+
+    def _path(self, document_id: str) -> str:
+        import hashlib
+
+        return os.path.join(self.dir, hashlib.sha1(document_id.encode("utf-8")).hexdigest() + ".json")
+
+    def upsert(self, doc: dict) -> None:
+        os.makedirs(self.dir, exist_ok=True)
+        cur = self.find(doc["document_id"]) or {}
+        cur.update(doc)
+        row = {k: (v.isoformat() if isinstance(v, datetime.datetime) else v) for k, v in cur.items()}
+        path = self._path(doc["document_id"])
+        tmp = f"{path}.tmp{os.getpid()}.{threading.get_ident()}"
+        with open(tmp, "w", encoding="utf-8") as f:
+            json.dump(row, f)
+        os.replace(tmp, path)
+
+    def find(self, document_id: str) -> Optional[dict]:
+        try:
+            with open(self._path(document_id), "r", encoding="utf-8") as f:
+                row = json.load(f)
+        except FileNotFoundError:
+            return None
+        if isinstance(row.get("processed_at"), str):
+            try:
+                row["processed_at"] = datetime.datetime.fromisoformat(row["processed_at"])
+            except ValueError:
+                pass
+        return row
+
+    def ping(self) -> dict:
+        os.makedirs(self.dir, exist_ok=True)
+        if not os.access(self.dir, os.W_OK):
+            raise ConnectionError(f"result directory {self.dir} is not writable")
+        return {"ok": 1}
+
+
 class MongoResultStore(ResultStore):
     """pymongo-backed store; connection options follow ocr_service.py:134-137."""
 
