@@ -140,11 +140,13 @@ def main():
         ]
         for name, x_, w_, b_, kw in cases:
             res = {}
-            for cfg in (0, 32, 64, 128, 1064, 1128, 2032, 3064, 3128, 4128):
+            for cfg in (0, 32, 64, 128, 1064, 1128, 2032, 3064, 3128, 4128, 7128, 7256):
                 if cfg in (32,) and w_.shape[0] > 64:
                     continue
                 patch_ok = (w_.shape[1] == 3 and w_.shape[2] == 3 and C._pair(kw['stride'])[1] == 1 and x_.shape[3] % 64 == 0)
-                if cfg >= 3000 and not patch_ok:
+                if 3000 <= cfg < 7000 and not patch_ok:
+                    continue
+                if cfg >= 7000 and x_.shape[3] % 64 != 0:
                     continue
                 res[cfg] = round(timed(lambda: C.conv2d_nhwc(x_, w_, b_, cfg=cfg, **kw), max(3, args.iters // 2), 2), 4)
             Bx, Hx, Wx, Cin = x_.shape

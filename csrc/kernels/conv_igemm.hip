@@ -19,6 +19,8 @@
 // (loads of K-tile t+1 are in flight while tile t is multiplied), one barrier
 // per K-tile, LDS double buffered.  Tile ids are remapped so that each XCD
 // (private L2) walks a contiguous range of output tiles.
+#include <stdlib.h>
+
 #include "common.h"
 
 struct ConvArgs {
@@ -356,11 +358,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 
   // ---------------- epilogue ----------------
   // acc[i][j][q]: channel n0 + wn*TN + i*16 + fq*4 + q, pixel m0 + wm*TM + j*16 + frow
+  if constexpr (FM <= 4) {
 #pragma unroll
-  for (int j = 0; j < FM; ++j) {
-    const int m = m0 + wm * TM + j * 16 + frow;
-    if (m >= p.M) continue;
-    conv_epilogue_pixel<FN, FM>(p, acc, j, m, n0 + wn * TN, fq);
+    for (int j = 0; j < FM; ++j) {
+      const int m = m0 + wm * TM + j * 16 + frow;
+      if (m >= p.M) continue;
+      conv_epilogue_pixel<FN, FM>(p, acc, j, m, n0 + wn * TN, fq);
+    }
+  } else {
+    // tall per-wave tiles: rolled loop + accumulator rotation (see conv_glds_kernel: an unrolled epilogue of this
+    // size pushes acc[][j] into scratch, and a kernel with scratch runs 4-5x slower)
+#pragma nounroll
+    for (int j = 0; j < FM; ++j) {
+      const int m = m0 + wm * TM + j * 16 + frow;
+      if (m < p.M) conv_epilogue_pixel<FN, FM>(p, acc, 0, m, n0 + wn * TN, fq);
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int jj = 0; jj + 1 < FM; ++jj) acc[i][jj] = acc[i][jj + 1];
+    }
   }
 }
 
@@ -552,6 +568,165 @@ static int dispatch_patch(ConvArgs& a, hipStream_t stream) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Big-tile convolution staged by LDS-DMA (global_load_lds_dwordx4): 256 pixels x BN channels per 8-wave workgroup.
+//   * 7.6 KB (BN = 256) or 11.4 KB (BN = 128) of L2 traffic per MFLOP-tile instead of 24 KB,
+//   * BOTH operands go global -> LDS without touching a VGPR (the registers hold a 128 x 64 accumulator per
+//     wave instead), issued one K-tile ahead so a whole K-tile of MFMAs (~2000 cycles) covers their latency,
+//   * the im2col gather is the DMA's per-lane SOURCE address; taps that fall outside the image read a zero page,
+//   * an LDS-DMA wave-instruction writes 1 KiB contiguously (lane l -> byte 16 l), so the XOR swizzle is applied
+//     on the source side: lane (row = l >> 3, slot = l & 7) fetches chunk slot ^ (row & 7) of its row.
+// One barrier per 64-deep K-tile: s_waitcnt vmcnt(0) (the DMA of tile t+1 has landed) + __syncthreads().
+// Measured (bench/conv_ktile_probe.py, profiles/06): the main loop runs at 1190-1310 TFLOP/s against 880-900 for
+// the 64 x 128 kernel, but with one 128 KB workgroup per CU nothing overlaps a tile's prologue and epilogue, so
+// at the K depths of this model (9-72 K-tiles) the whole launch only ties (K >= 36) or loses; a persistent
+// variant that prefetched the next tile under the epilogue did not change that.  Kept as explicit configs
+// (7256 / 7128) for deeper-K models; auto mode does not pick it.
+__device__ __attribute__((aligned(256))) uint8_t dlamd_zero_page[256];
+
+template <int BN, int WM, int WN, bool IS_1X1>
+__global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs p) {
+  constexpr int BM = 256, ROWB = 128;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int FM = TM / 16, FN = TN / 16;
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+  constexpr int PA = BM / 64, PB = BN / 64;          // DMA instructions per thread and K-tile (64 rows each)
+  static_assert(WM * WN == 8 && TM % 16 == 0 && TN % 16 == 0, "8 waves");
+  extern __shared__ __attribute__((aligned(1024))) char smem[];   // 2 stages x (pixels | weights)
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int tile = dlamd_xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nkt = p.K >> 6;
+
+  // loader role of this lane: row rp of every 64-row pass, 16-byte chunk ch of the 128-byte K row
+  const int rp = tid >> 3;
+  const int ch = (tid & 7) ^ (rp & 7);
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(dlamd_zero_page);
+
+  long long a_base[PA];
+  int a_hi0[PA], a_wi0[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int m = m0 + rp + 64 * i;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    const int hw = p.Ho * p.Wo;
+    const int b = mm / hw, rem = mm - b * hw;
+    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    a_hi0[i] = ok ? ho * p.sh - p.ph : -(1 << 28);      // rows past M fail the bounds test -> zero page
+    a_wi0[i] = wo * p.sw - p.pw;
+    a_base[i] = ((long long)(b * p.H + (ho * p.sh - p.ph)) * p.W + a_wi0[i]) * p.x_cstride + ch * 8;
+  }
+  const bf16_t* b_src[PB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int n = n0 + rp + 64 * i;
+    b_src[i] = n < p.Cout ? p.w + (long long)n * p.K + ch * 8 : nullptr;
+  }
+
+  auto issue_tile = [&](int kt, int stage) {
+    int dy = 0, dx = 0, cin0 = kt * 64;
+    if (!IS_1X1) {
+      const int tap = cin0 / p.Cin;
+      cin0 -= tap * p.Cin;
+      dy = tap / p.kw;
+      dx = tap - dy * p.kw;
+    }
+    const long long off = (long long)(dy * p.W + dx) * p.x_cstride + cin0;
+    char* sa = smem + stage * STAGE + wid * 1024;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const bool v = (unsigned)(a_hi0[i] + dy) < (unsigned)p.H && (unsigned)(a_wi0[i] + dx) < (unsigned)p.W;
+      const bf16_t* src = v ? p.x + a_base[i] + off : zero;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sa + i * 64 * ROWB), 16, 0, 0);
+    }
+    char* sb = smem + stage * STAGE + A_BYTES + wid * 1024;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const bf16_t* src = b_src[i] ? b_src[i] + kt * 64 : zero;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sb + i * 64 * ROWB), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue_tile(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int stage = kt & 1;
+    if (kt + 1 < nkt) issue_tile(kt + 1, stage ^ 1);
+    const char* Ab = smem + stage * STAGE;
+    const char* Bb = Ab + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 wf[FN], xf[FM];
+      const int chunk = ks * 4 + fq;
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const int row = wn * TN + i * 16 + frow;
+        wf[i] = *reinterpret_cast<const bf16x8*>(Bb + row * ROWB + ((chunk ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        const int row = wm * TM + j * 16 + frow;
+        xf[j] = *reinterpret_cast<const bf16x8*>(Ab + row * ROWB + ((chunk ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile kt+1 has landed in the other stage
+    __syncthreads();                                      // ... for every wave, and stage kt is free to overwrite
+  }
+
+  // Epilogue as a ROLLED loop over the wave's pixel sub-tiles.  Unrolled, the fused epilogue is too large, the
+  // compiler then indexes acc[][j] in scratch memory - and a kernel that owns scratch ran 4-5x slower here
+  // whatever its main loop did (every big-tile variant with a non-zero ScratchSize, docs/KERNELS.md).
+  // So the loop always consumes acc[.][0] and then rotates the tiles down.
+#pragma nounroll
+  for (int j = 0; j < FM; ++j) {
+    const int m = m0 + wm * TM + j * 16 + frow;
+    if (m < p.M) conv_epilogue_pixel<FN, FM>(p, acc, 0, m, n0 + wn * TN, fq);
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int jj = 0; jj + 1 < FM; ++jj) acc[i][jj] = acc[i][jj + 1];
+  }
+}
+
+template <int BN, int WM, int WN, bool IS_1X1>
+static int launch_glds(ConvArgs& a, hipStream_t stream) {
+  if (a.Cin % 64 != 0 || a.K % 64 != 0) return -16;        // a 64-deep K tile must lie inside one filter tap
+  a.tiles_m = (a.M + 255) / 256;
+  a.tiles_n = (a.Cout + BN - 1) / BN;
+  const size_t smem = 2 * (256 + BN) * 128;
+  auto kern = conv_glds_kernel<BN, WM, WN, IS_1X1>;
+  static bool set = false;
+  if (!set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return -2;
+    set = true;
+  }
+  long long grid = (long long)a.tiles_m * a.tiles_n;
+  if (grid <= 0 || grid > 0x7fffffffLL) return -3;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, a);
+  return DLAMD_CHECK_LAUNCH();
+}
+
 template <int BM, int BN, int WM, int WN, bool IS_1X1, bool B_DIRECT, int BKT>
 static int launch_impl(ConvArgs& a, hipStream_t stream) {
   a.tiles_m = (a.M + BM - 1) / BM;
@@ -614,9 +789,12 @@ static int dispatch(ConvArgs& a, hipStream_t stream, int cfg) {
                  // except on 512->512 (fewer barriers, but 132 VGPRs -> 3 waves/SIMD), so auto never picks it
       if (!a.wfrag) return -14;
       return launch_impl<64, 128, 1, 4, IS_1X1, true, 128>(a, stream);
-    // Bigger tiles (128x128, 256x128, 128x256 with direct weights) were measured and dropped: 1.3x (128x128) to
-    // 4-5x (256-wide) SLOWER than 64x128 on every layer (profiles/06_conv_tile_sweep.txt) - this loop hides
-    // global-load latency with resident blocks per CU, not with software pipelining, and big tiles cut those.
+    case 7256: return launch_glds<256, 2, 4, IS_1X1>(a, stream);     // 256 x 256, LDS-DMA staged, 8 waves
+    case 7128: return launch_glds<128, 4, 2, IS_1X1>(a, stream);     // 256 x 128
+    // Bigger REGISTER-staged tiles with direct weights (128x128, 256x128, 128x256 as 1x4 waves) were measured
+    // twice and dropped (profiles/06_conv_tile_sweep.txt): first 4-5x slower because their unrolled epilogue put
+    // the accumulators in scratch, then - scratch-free, rolled epilogue - still 1.25x / 2x / 1.6x slower than
+    // 64x128: their accumulators (68-132 AGPRs) cut the resident workgroups this loop needs to hide latency.
     default: return -4;
   }
 }
@@ -677,6 +855,12 @@ extern "C" int dlamd_conv2d(const void* x, const void* w, const float* bias, con
     return wide ? dispatch_patch<2, 128, 2, 2>(a, stream) : dispatch_patch<2, 64, 4, 1>(a, stream);
   }
   if (cfg == 3064 || cfg == 3128) return -13;
+  // Deep-K, 256-multiple-Cout 3x3 layers (CRNN c4 / c5): the LDS-DMA 256 x 256 kernel wins by 2-5 % (sweep 4 in
+  // profiles/06_conv_tile_sweep.txt); everywhere else its un-overlapped prologue / epilogue loses.
+  static const bool glds_auto = getenv("DLAMD_CONV_GLDS") != nullptr && atoi(getenv("DLAMD_CONV_GLDS")) != 0;
+  if (glds_auto && cfg == 0 && Cin % 64 == 0 && Cout % 256 == 0 && a.K >= 36 * 64 && kh == 3 && kw == 3 &&
+      (long long)((a.M + 255) / 256) * (Cout / 256) >= 1024)
+    cfg = 7256;
   if (cfg == 3900) cfg = 0;
   const bool is1x1 = (kh == 1 && kw == 1 && ph == 0 && pw == 0);
   return is1x1 ? dispatch<true>(a, stream, cfg) : dispatch<false>(a, stream, cfg);

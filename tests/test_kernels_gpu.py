@@ -50,6 +50,8 @@ def test_conv_matches_reference(case):
     cfgs = [0, 16, 32, 64, 128, 1064, 1128, 2032, 3900, 4128]    # 4xxx: 128-deep K tile
     if k == 3 and p == 1 and s == 1 and Cin % 64 == 0:
         cfgs += [3064, 3128]          # LDS-patch 3x3 kernel, both channel-tile widths
+    if Cin % 64 == 0:
+        cfgs += [7128, 7256]          # 256-pixel tiles staged by LDS-DMA (global_load_lds), 8 waves
     for cfg in cfgs:
         out = C.conv2d_nhwc(x.to(DEV), w.to(DEV), b.to(DEV), stride=s, padding=p, act=act, cfg=cfg)
         assert out.shape == ref.shape
