@@ -94,3 +94,32 @@ def test_dead_worker_is_respawned_and_its_shards_requeued():
         assert d["restarts"] >= 1
     finally:
         p.stop()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_gpu_worker_processes_shard_a_scanned_document():
+    """Two worker PROCESSES on the GPU (both on cuda:0 on a one-GPU box - the 8-GPU node gives each its own device):
+    shared-memory hand-off of the PDF, page shards, ordered gather; full-size models with the shipped weights, and
+    the gathered text must equal what the in-process engine reads."""
+    from pathlib import Path
+
+    from distributed_llms_amd.runtime.document import DocumentPipeline
+    from distributed_llms_amd.runtime.workers import build_engine
+
+    wd = Path(__file__).resolve().parents[1] / "weights"
+    spec = {"model": "full", "cfg": dict(max_batch_pages=4), "weights_dir": str(wd) if wd.exists() else None}
+    rendered = [synth.render_page(500 + i)[0] for i in range(3)]
+    pages = [rendered[i % 3] for i in range(12)]
+    pdf = synth.make_scanned_pdf(pages, codec="jpeg")
+    pool = WorkerPool(["cuda:0", "cuda:0"], spec, max_wait_ms=5.0, min_pages_per_shard=4, doc_deadline_s=240.0).start(240.0)
+    try:
+        doc = PoolExtractor(pool).extract_document(pdf, "g1")
+        assert doc.mode == "ocr" and [p.page_index for p in doc.pages] == list(range(12))
+        d = pool.describe()
+        assert d["pages_done"] >= 12 and d["alive"] == 2
+    finally:
+        pool.stop()
+    ref = DocumentPipeline(build_engine("cuda:0", spec)).process_pdf(pdf, "ref")
+    assert [len(p.lines) for p in doc.pages] == [len(p.lines) for p in ref.pages]
+    assert doc.text == ref.text
