@@ -47,6 +47,7 @@ struct ConvArgs {
   const bf16_t* wfrag;  // weights pre-swizzled to MFMA fragment order [N/16][Kpad/32][64][8] (or nullptr)
   int k32;          // Kpad / 32
   int n16;          // padded Cout / 16: 16-row weight tiles that exist in wfrag (tile reads are clamped to it)
+  int coalesce;     // plain bf16 store whose rows are 16-byte aligned: stage the output tile in LDS, store full lines
 };
 
 static constexpr int BK = 64;  // K elements per tile (128 B per LDS row)
@@ -54,9 +55,19 @@ static constexpr int BK = 64;  // K elements per tile (128 B per LDS row)
 // Fused epilogue for one output pixel m held by this lane: bias + residual (+ nearest-2x upsampled residual) +
 // activation, then one of the store modes (plain / concat offset, pixel-shuffle, replicate, prob-map + mask).
 // acc[i][j][q] is channel nbase + i*16 + fq*4 + q of that pixel.
+// Where the epilogue puts a plain bf16 result: straight to global memory (8 bytes per lane: a wave instruction is
+// 16 pixel rows x 32 bytes, i.e. 16 partial-line requests) or into an LDS image of the output tile that the
+// workgroup then writes out as whole 16-byte-per-lane rows.  The partial-line form costs ~1.25 ps per output
+// element whatever the K depth - 25-30 % of an 18-K-tile layer (bench/conv_ktile_probe.py).
+struct ConvLdsSink {
+  char* base;      // LDS image [rows][rowb bytes], nullptr: store to global
+  int m0, n0, rowb;
+};
+
 template <int FN, int FM>
 __device__ __forceinline__ void conv_epilogue_pixel(const ConvArgs& p, const f32x4 (&acc)[FN][FM], const int j,
-                                                    const int m, const int nbase, const int fq) {
+                                                    const int m, const int nbase, const int fq,
+                                                    const ConvLdsSink sink = ConvLdsSink{nullptr, 0, 0, 0}) {
   const int hw = p.Ho * p.Wo;
   int b = 0, ho = 0, wo = 0;
   if (p.out_mode != 0 || p.res_mode == 2) {
@@ -117,7 +128,8 @@ __device__ __forceinline__ void conv_epilogue_pixel(const ConvArgs& p, const f32
     bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
     bf16_t* yp = reinterpret_cast<bf16_t*>(p.y);
     if (p.out_mode == 0) {
-      *reinterpret_cast<bf16x4*>(yp + (long long)m * p.y_cstride + p.y_coff + n) = o;
+      if (sink.base) *reinterpret_cast<bf16x4*>(sink.base + (m - sink.m0) * sink.rowb + (n - sink.n0) * 2) = o;
+      else *reinterpret_cast<bf16x4*>(yp + (long long)m * p.y_cstride + p.y_coff + n) = o;
     } else if (p.out_mode == 1) {
       const int Cp = p.Cout >> 2;
       const int g = n / Cp, cc = n - g * Cp;
@@ -132,6 +144,25 @@ __device__ __forceinline__ void conv_epilogue_pixel(const ConvArgs& p, const f32
           *reinterpret_cast<bf16x4*>(yp + pix * p.y_cstride + p.y_coff + n) = o;
         }
     }
+  }
+}
+
+// Writes the LDS image of a BM x BN bf16 output tile to global memory: 16 bytes per lane, consecutive lanes along
+// the channel row, so a wave instruction covers whole 128-byte lines.  All 256 threads call it after a barrier.
+template <int BM, int BN>
+__device__ __forceinline__ void conv_store_tile_from_lds(const ConvArgs& p, const char* img, const int rowb, const int m0,
+                                                         const int n0, const int tid) {
+  constexpr int CPR = BN / 8;                 // 16-byte chunks per row
+  bf16_t* yp = reinterpret_cast<bf16_t*>(p.y);
+#pragma unroll
+  for (int q = tid; q < BM * CPR; q += 256) {
+    const int row = q / CPR, cc = q - row * CPR;
+    const int m = m0 + row, n = n0 + cc * 8;
+    if (m >= p.M || n >= p.Cout) continue;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(img + row * rowb + cc * 16);
+    bf16_t* dst = yp + (long long)m * p.y_cstride + p.y_coff + n;
+    if (n + 8 <= p.Cout) *reinterpret_cast<u32x4*>(dst) = v;
+    else *reinterpret_cast<u32x2*>(dst) = u32x2{v[0], v[1]};      // Cout % 8 == 4: the last chunk is half valid
   }
 }
 
@@ -359,11 +390,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   // ---------------- epilogue ----------------
   // acc[i][j][q]: channel n0 + wn*TN + i*16 + fq*4 + q, pixel m0 + wm*TM + j*16 + frow
   if constexpr (FM <= 4) {
+    // the K loop ended on a barrier: the operand buffers are free and become the output image
+    constexpr int OROWB = BN * 2 + 16;          // padded rows: the 16 pixel rows of a fragment spread over the banks
+    const ConvLdsSink sink{p.coalesce ? smem : nullptr, m0, n0, OROWB};
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
       const int m = m0 + wm * TM + j * 16 + frow;
       if (m >= p.M) continue;
-      conv_epilogue_pixel<FN, FM>(p, acc, j, m, n0 + wn * TN, fq);
+      conv_epilogue_pixel<FN, FM>(p, acc, j, m, n0 + wn * TN, fq, sink);
+    }
+    if (p.coalesce) {
+      __syncthreads();
+      conv_store_tile_from_lds<BM, BN>(p, smem, OROWB, m0, n0, tid);
     }
   } else {
     // tall per-wave tiles: rolled loop + accumulator rotation (see conv_glds_kernel: an unrolled epilogue of this
@@ -735,6 +773,7 @@ static int launch_impl(ConvArgs& a, hipStream_t stream) {
   // K <= 64 (1x1 laterals, deconvs): one K tile, no double buffer -> half the LDS, twice the blocks per CU.
   a.nbuf = nkt == 1 ? 1 : 2;
   size_t smem = a.nbuf * (BM + (B_DIRECT ? 0 : BN)) * (BKT * 2) + (IS_1X1 ? 0 : size_t(nkt) * (BKT / 8) * 2 * sizeof(uint32_t));
+  if (a.coalesce && BM / WM / 16 <= 4) smem = smem > size_t(BM) * (BN * 2 + 16) ? smem : size_t(BM) * (BN * 2 + 16);
   auto kern = conv_igemm_kernel<BM, BN, WM, WN, IS_1X1, B_DIRECT, BKT>;
   static size_t max_set = 0;
   if (smem > 65536 && smem > max_set) {
@@ -835,6 +874,7 @@ extern "C" int dlamd_conv2d(const void* x, const void* w, const float* bias, con
   a.y_coff = y_coff;
   a.y_f32 = y_f32;
   a.thr = thr;
+  a.coalesce = (out_mode == 0 && !y_f32 && y_cstride % 8 == 0 && y_coff % 8 == 0) ? 1 : 0;
   // Host-side shape contract of the kernel (16-byte vector loads / 8-byte stores).
   if (Cin % 8 != 0 || x_cstride % 8 != 0 || a.K % 8 != 0) return -6;
   if (out_mode == 3) { if (Cout != 4 || mask == nullptr) return -7; }
