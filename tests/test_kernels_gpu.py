@@ -47,7 +47,7 @@ def test_conv_matches_reference(case):
     b = torch.randn(Cout, generator=torch.Generator().manual_seed(3)) * 0.1
     ref = C.conv2d_nhwc_reference(x, w, b, stride=s, padding=p, act=act, out_dtype=torch.float32)
     # cfg 0 = the dispatcher's own choice; the explicit ids force every tile shape onto every problem
-    cfgs = [0, 16, 32, 64, 128, 1064, 1128, 2032, 3900, 4128]    # 4xxx: 128-deep K tile
+    cfgs = [0, 16, 32, 64, 128, 1064, 1128, 2032, 3900, 4128, 8128]    # 4xxx: 128-deep K tile
     if k == 3 and p == 1 and s == 1 and Cin % 64 == 0:
         cfgs += [3064, 3128]          # LDS-patch 3x3 kernel, both channel-tile widths
     if Cin % 64 == 0:
@@ -86,6 +86,26 @@ def test_conv3x3_patch_kernel_shapes_strides_and_fusions(shape, cfg):
                       out_coff=16, cfg=cfg)
         _close(cat[..., 16 : 16 + Cout], ref2)
         assert cat[..., :16].abs().max().item() == 0 and cat[..., 16 + Cout :].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("case", [(2, 40, 48, 64, 128, 3, 1, 1), (1, 33, 29, 64, 64, 3, 2, 1), (2, 20, 28, 64, 256, 1, 1, 0),
+                                  (1, 16, 24, 128, 256, 3, 1, 1)])
+def test_conv_persistent_kernel_walks_several_tiles_per_workgroup(case, monkeypatch):
+    """cfg 8128 with the grid forced down to 5 workgroups: every workgroup processes many output tiles in turn
+    (tap table reused, LDS output image and operand buffers recycled between tiles)."""
+    B, H, W, Cin, Cout, k, s, p = case
+    monkeypatch.setenv("DLAMD_CONV_PERSIST_GRID", "5")
+    x = _rand_bf16(B, H, W, Cin, seed=31)
+    w = _rand_bf16(Cout, k, k, Cin, scale=(2.0 / (k * k * Cin)) ** 0.5, seed=32)
+    b = torch.randn(Cout, generator=torch.Generator().manual_seed(33)) * 0.1
+    ref = C.conv2d_nhwc_reference(x, w, b, stride=s, padding=p, act="relu", out_dtype=torch.float32)
+    out = C.conv2d_nhwc(x.to(DEV), w.to(DEV), b.to(DEV), stride=s, padding=p, act="relu", cfg=8128)
+    _close(out, ref)
+    res = _rand_bf16(*out.shape, seed=34)
+    ref2 = C.conv2d_nhwc_reference(x, w, b, stride=s, padding=p, act="relu", res=res, res_mode=C.RES_SAME, out_dtype=torch.float32)
+    out2 = C.conv2d_nhwc(x.to(DEV), w.to(DEV), b.to(DEV), stride=s, padding=p, act="relu", res=res.to(DEV), res_mode=C.RES_SAME,
+                         cfg=8128, out_dtype=torch.float32)           # f32 output: the direct (non-LDS-image) store path
+    _close(out2, ref2)
 
 
 def test_conv_asymmetric_kernel_and_stride():
