@@ -28,6 +28,7 @@ RES_NONE, RES_SAME, RES_UP2 = 0, 1, 2
 IntPair = Union[int, Tuple[int, int]]
 
 USE_WEIGHT_FRAGMENTS = True
+LIBRARY_GEMM_MIN_ROWS = 4096      # 0: never call the library GEMM
 
 
 def weight_fragments(w: torch.Tensor) -> torch.Tensor:
@@ -234,6 +235,23 @@ def linear_bf16(
     lead = x.shape[:-1]
     K = x.shape[-1]
     N = w.shape[0]
+    # A PLAIN GEMM (bias only: no activation, residual or store transform to fuse) with many rows is the one case
+    # a library kernel is the right tool: hipBLASLt runs the LSTM input projections at 705 TFLOP/s and the ViT
+    # QKV GEMMs at 1135 against 421 / 527 for the 1x1 path of conv_igemm (bench/gemm_probe.py).  Everything
+    # fused, and the small-M decode GEMMs (captured in hipGraphs), stay on the in-repo kernel.
+    if (LIBRARY_GEMM_MIN_ROWS > 0 and x.is_cuda and act == "none" and res is None and out_dtype == torch.bfloat16
+            and x.numel() // K >= LIBRARY_GEMM_MIN_ROWS and w.is_contiguous()):
+        b16 = None
+        if bias is not None:
+            cached = getattr(bias, "_dlamd_bf16", None)
+            if cached is None or cached[0] != bias._version:
+                cached = (bias._version, bias.detach().to(torch.bfloat16))
+                try:
+                    bias._dlamd_bf16 = cached
+                except Exception:  # noqa: BLE001
+                    pass
+            b16 = cached[1][:N]
+        return F.linear(x.reshape(-1, K), w, b16).reshape(*lead, N)
     x2 = x.reshape(1, 1, -1, K)
     r2 = None if res is None else res.reshape(1, 1, -1, N)
     y = conv2d_nhwc(
