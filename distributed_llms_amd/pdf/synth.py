@@ -207,10 +207,16 @@ def encode_page_jpeg(page: np.ndarray, quality: int = 85, restart_blocks: int = 
 
 def make_scanned_pdf(pages: Sequence[np.ndarray], codec: str = "jpeg", quality: int = 85, dpi: int = 300,
                      restart_blocks: int = 62, xref_stream: bool = False,
-                     encoded: Optional[Sequence[bytes]] = None) -> bytes:
+                     encoded: Optional[Sequence[bytes]] = None, rotate: int = 0) -> bytes:
     """PDF with one full-page image per page.  ``pages``: uint8 [H, W] (gray) or [H, W, 3] arrays.
 
-    ``encoded`` may carry pre-encoded image streams (same order) to avoid re-encoding."""
+    ``encoded`` may carry pre-encoded image streams (same order) to avoid re-encoding.
+    ``rotate`` (0/90/180/270): what a scanner's "landscape feed" produces - the stored raster is turned
+    counter-clockwise by that angle and the page carries ``/Rotate`` so that a viewer shows it upright."""
+    assert rotate in (0, 90, 180, 270)
+    if rotate:
+        assert encoded is None
+        pages = [np.ascontiguousarray(np.rot90(pg, k=rotate // 90)) for pg in pages]
     w = _PdfWriter()
     catalog = w.reserve()
     pages_id = w.reserve()
@@ -234,7 +240,7 @@ def make_scanned_pdf(pages: Sequence[np.ndarray], codec: str = "jpeg", quality: 
         cid = w.add(w.stream(b"", content))
         pid = w.add(
             b"<< /Type /Page /Parent %d 0 R /MediaBox [0 0 %.2f %.2f] /Resources << /XObject << /Im0 %d 0 R >> >> "
-            b"/Contents %d 0 R >>" % (pages_id, wpt, hpt, img, cid))
+            b"/Contents %d 0 R%s >>" % (pages_id, wpt, hpt, img, cid, b" /Rotate %d" % rotate if rotate else b""))
         kids.append(pid)
     w.set(pages_id, b"<< /Type /Pages /Count %d /Kids [%s] >>" % (len(kids), b" ".join(b"%d 0 R" % k for k in kids)))
     w.set(catalog, b"<< /Type /Catalog /Pages %d 0 R >>" % pages_id)

@@ -113,6 +113,13 @@ class DocumentPipeline:
         im = doc.main_image(i)
         if im is None:
             return None
+        page = self._load_raster(doc, im, i, doc_id, prior)
+        rot = int(doc.page_info(i).rotate) % 360
+        if rot in (90, 180, 270):
+            page.rotation = rot
+        return page
+
+    def _load_raster(self, doc: reader.PdfDocument, im, i: int, doc_id: str, prior) -> PageImage:
         if im.codec == reader.CODEC_JPEG:
             stream = doc.jpeg_bytes(im)
             scan = reader.scan_jpeg(stream)

@@ -55,13 +55,20 @@ class PageImage:
     page_index: int = 0
     layout_prior: Optional[np.ndarray] = None  # [n, 4] x0,y0,x1,y1 in page pixels (see module docstring)
     encoded: Optional[tuple] = None
+    rotation: int = 0          # the page's /Rotate: degrees clockwise the stored raster must be turned to read upright
 
     @property
-    def hw(self) -> Tuple[int, int]:
+    def raster_hw(self) -> Tuple[int, int]:
         if self.image is not None:
             return int(self.image.shape[0]), int(self.image.shape[1])
         info = self.encoded[1].info
         return int(info.height), int(info.width)
+
+    @property
+    def hw(self) -> Tuple[int, int]:
+        """Upright page size (what detection boxes refer to)."""
+        h, w = self.raster_hw
+        return (w, h) if self.rotation in (90, 270) else (h, w)
 
 
 @dataclass
@@ -193,6 +200,10 @@ class OcrEngine:
                     img = p.image
                     if img.device != self.device:
                         img = img.to(self.device, non_blocking=True)
+                    srcs[i] = img
+                if p.rotation:
+                    # /Rotate: turn the decoded raster upright on the device once; crops then come from the same copy
+                    img = torch.rot90(img, k=-(p.rotation // 90), dims=(0, 1)).contiguous()
                     srcs[i] = img
                 regions.append(rs.Region(img, (0.0, 0.0, float(img.shape[1]), float(img.shape[0])), oh, ow))
             x = self._resample(regions, Hd, Wd, rs.IMAGENET_MEAN, rs.IMAGENET_STD)

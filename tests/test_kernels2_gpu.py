@@ -171,6 +171,10 @@ def test_engine_end_to_end_scanned_pdf():
     eng2 = OcrEngine(DEV, cfg=EngineConfig(max_batch_pages=2, det_limit_side=960, use_hip_graphs=False))
     doc3 = DocumentPipeline(eng2, decode_threads=2).process_pdf(pdf, "t", layout_priors=priors)
     assert doc3.text == first
+    # /Rotate: the sideways-stored (lossless) scan reads exactly like the upright one
+    up = pipe.process_pdf(synth.make_scanned_pdf(pages, codec="flate", dpi=150), "t", layout_priors=priors)
+    rot = pipe.process_pdf(synth.make_scanned_pdf(pages, codec="flate", dpi=150, rotate=270), "t", layout_priors=priors)
+    assert rot.text == up.text
     # crops that all share one width bucket replay a captured graph (several buckets go through the ragged pass:
     # per-bucket launches would serialise the recurrence); the replay must read what the eager path reads
     one = [b[:1] for b in priors]

@@ -190,3 +190,27 @@ def test_image_formats_bilevel_indexed_predictor():
 def test_short_born_digital_document_is_text_not_ocr():
     with reader.PdfDocument(synth.make_text_pdf([["Tiny note."]])) as d:
         assert d.classify().is_text
+
+
+@pytest.mark.parametrize("rotate", [90, 180, 270])
+def test_rotated_scans_are_read_upright(rotate):
+    """A page stored sideways with /Rotate (a scanner's landscape feed) must give the same lines as the upright
+    scan: the reader reports the angle, the pipeline turns the raster before detection and cropping."""
+    import torch
+
+    from distributed_llms_amd.runtime.document import DocumentPipeline
+    from distributed_llms_amd.runtime.workers import build_engine
+
+    rendered = [synth.render_page(40 + i, size=(248, 350), font_px=10, margin=16) for i in range(2)]
+    pages = [p for p, _ in rendered]
+    priors = [t.boxes for _, t in rendered]
+    eng = build_engine("cpu", {"model": "tiny", "cfg": dict(det_limit_side=160, rec_max_width=256, rec_width_quantum=64,
+                                                             max_batch_pages=2)})
+    pipe = DocumentPipeline(eng, decode_threads=2)
+    up = pipe.process_pdf(synth.make_scanned_pdf(pages, codec="flate", dpi=30), "up", layout_priors=priors)
+    pdf = synth.make_scanned_pdf(pages, codec="flate", dpi=30, rotate=rotate)
+    with reader.PdfDocument(pdf) as doc:
+        assert doc.page_info(0).rotate == rotate
+    rot = pipe.process_pdf(pdf, "rot", layout_priors=priors)
+    assert [(p.width, p.height) for p in rot.pages] == [(p.width, p.height) for p in up.pages]
+    assert rot.text == up.text and len(rot.pages[0].lines) == len(priors[0])
