@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <mutex>
 
+#include "ccitt_fax.h"
 #include "jpeg_scan.h"
 #include "pdf_content.h"
 
@@ -147,6 +148,21 @@ ImageDesc describe_image(Document& doc, int obj_num, const ImagePlacement& pl) {
       im.parms.push_back(pr);
       continue;
     }
+    if (fn == "CCITTFaxDecode" || fn == "CCF") {
+      // K, Columns, Rows, BlackIs1, EncodedByteAlign (defaults of the PDF specification)
+      std::array<int, 5> pr = {0, 1728, 0, 0, 0};
+      if (parms[i] && parms[i]->type == Obj::Dict) {
+        pr[0] = (int)to_int(doc.dget(parms[i], "K"), 0);
+        pr[1] = (int)to_int(doc.dget(parms[i], "Columns"), 1728);
+        pr[2] = (int)to_int(doc.dget(parms[i], "Rows"), 0);
+        ObjP b1 = doc.dget(parms[i], "BlackIs1"), ba = doc.dget(parms[i], "EncodedByteAlign");
+        pr[3] = b1 && b1->type == Obj::Bool && b1->b ? 1 : 0;
+        pr[4] = ba && ba->type == Obj::Bool && ba->b ? 1 : 0;
+      }
+      im.filters.push_back("CCITTFaxDecode");
+      im.parms.push_back(pr);
+      continue;
+    }
     im.codec = 2;
     im.unsupported_reason = "image codec " + fn + " is not supported";
     break;
@@ -173,6 +189,14 @@ std::string run_filters(const uint8_t* file, const ImageDesc& im) {
     const uint8_t* ip = have ? (const uint8_t*)cur.data() : p;
     size_t il = have ? cur.size() : len;
     std::string next;
+    if (fn == "CCITTFaxDecode") {
+      const auto& pr = im.parms[i];
+      const int rows = pr[2] > 0 ? pr[2] : im.height;
+      next = ccitt::decode(ip, il, pr[0], pr[1], rows, pr[3] != 0, pr[4] != 0, im.height > 0 ? im.height : (1 << 16));
+      cur.swap(next);
+      have = true;
+      continue;
+    }
     if (fn == "FlateDecode" || fn == "Fl") {
       size_t hint = ((size_t)im.width * im.ncomp * im.bpc + 7) / 8 * im.height + im.height + 64;
       next = inflate_bytes(ip, il, i + 1 == im.filters.size() ? hint : 0);

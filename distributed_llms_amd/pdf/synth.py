@@ -205,6 +205,24 @@ def encode_page_jpeg(page: np.ndarray, quality: int = 85, restart_blocks: int = 
     return buf.getvalue()
 
 
+def encode_page_ccitt_g4(page: np.ndarray, threshold: int = 128) -> Tuple[bytes, bool]:
+    """Gray page -> (Group 4 fax strip, BlackIs1 flag for the PDF image) through PIL's libtiff writer (one strip)."""
+    import io
+
+    from PIL import Image
+
+    gray = page if page.ndim == 2 else page.mean(axis=2)
+    im = Image.fromarray(((gray >= threshold) * 255).astype(np.uint8)).convert("1")
+    buf = io.BytesIO()
+    im.save(buf, format="TIFF", compression="group4", tiffinfo={278: im.height})
+    raw = buf.getvalue()
+    t = Image.open(io.BytesIO(raw))
+    offs, cnts = t.tag_v2[273], t.tag_v2[279]
+    assert len(offs) == 1, "expected a single strip"
+    # photometric 1 (BlackIsZero): the coder's "white" runs are the file's 0 bits = black pixels
+    return raw[offs[0] : offs[0] + cnts[0]], int(t.tag_v2.get(262, 0)) == 1
+
+
 def make_scanned_pdf(pages: Sequence[np.ndarray], codec: str = "jpeg", quality: int = 85, dpi: int = 300,
                      restart_blocks: int = 62, xref_stream: bool = False,
                      encoded: Optional[Sequence[bytes]] = None, rotate: int = 0) -> bytes:
@@ -230,11 +248,20 @@ def make_scanned_pdf(pages: Sequence[np.ndarray], codec: str = "jpeg", quality: 
         elif codec == "flate":
             data = encoded[i] if encoded is not None else zlib.compress(np.ascontiguousarray(pg).tobytes(), 1)
             flt = b"/FlateDecode"
+        elif codec == "ccitt":
+            # bilevel Group 4 fax data, what office scanners emit for black-and-white scans
+            data, black_is_1 = encode_page_ccitt_g4(pg)
+            img = w.add(w.stream(
+                b"/Type /XObject /Subtype /Image /Width %d /Height %d /ColorSpace /DeviceGray /BitsPerComponent 1 "
+                b"/Filter /CCITTFaxDecode /DecodeParms << /K -1 /Columns %d /Rows %d /BlackIs1 %s >>"
+                % (W, H, W, H, b"true" if black_is_1 else b"false"), data))
+            flt = None
         else:
-            raise ValueError("codec must be jpeg or flate")
-        img = w.add(w.stream(
-            b"/Type /XObject /Subtype /Image /Width %d /Height %d /ColorSpace %s /BitsPerComponent 8 /Filter %s"
-            % (W, H, cs, flt), data))
+            raise ValueError("codec must be jpeg, flate or ccitt")
+        if flt is not None:
+            img = w.add(w.stream(
+                b"/Type /XObject /Subtype /Image /Width %d /Height %d /ColorSpace %s /BitsPerComponent 8 /Filter %s"
+                % (W, H, cs, flt), data))
         wpt, hpt = W * 72.0 / dpi, H * 72.0 / dpi
         content = b"q %.2f 0 0 %.2f 0 0 cm /Im0 Do Q" % (wpt, hpt)
         cid = w.add(w.stream(b"", content))

@@ -47,7 +47,7 @@ def seed_documents(tmp: Path):
         p.write_bytes(synth.make_text_pdf(texts, **kw))
         paths.append(p)
     pages = [synth.render_page(s, size=(310, 438), font_px=12, margin=16)[0] for s in (1, 2)]
-    for codec in ("jpeg", "flate"):
+    for codec in ("jpeg", "flate", "ccitt"):
         p = tmp / f"scan_{codec}.pdf"
         p.write_bytes(synth.make_scanned_pdf(pages, codec=codec))
         paths.append(p)

@@ -214,3 +214,48 @@ def test_rotated_scans_are_read_upright(rotate):
     rot = pipe.process_pdf(pdf, "rot", layout_priors=priors)
     assert [(p.width, p.height) for p in rot.pages] == [(p.width, p.height) for p in up.pages]
     assert rot.text == up.text and len(rot.pages[0].lines) == len(priors[0])
+
+
+def _bilevel(seed, H, W):
+    pg, _ = synth.render_page(seed, size=(W, H), font_px=14, margin=20, noise=0.0)
+    return pg
+
+
+@pytest.mark.parametrize("hw", [(350, 248), (97, 131), (64, 2600)])
+def test_ccitt_group4_scans_decode_exactly(hw):
+    """CCITTFaxDecode /K -1 (what office scanners write for black-and-white pages): the native decoder must
+    reproduce the bilevel page bit for bit (encoder: PIL/libtiff)."""
+    H, W = hw
+    rng = np.random.default_rng(H * 7 + W)
+    pages = [_bilevel(3, H, W), ((rng.random((H, W)) > 0.35) * 255).astype(np.uint8),          # text; dense noise
+             np.full((H, W), 255, np.uint8), np.zeros((H, W), np.uint8)]                         # all white; all black
+    pages[1][:, : W // 3] = 255                                                                   # long white runs too
+    pdf = synth.make_scanned_pdf(pages, codec="ccitt", dpi=72)
+    with reader.PdfDocument(pdf) as doc:
+        assert doc.page_count == len(pages)
+        for i, pg in enumerate(pages):
+            im = doc.main_image(i)
+            assert im is not None and im.codec == reader.CODEC_RAW and (im.width, im.height) == (W, H)
+            got = doc.decode_image(im)
+            want = ((pg >= 128) * 255).astype(np.uint8)
+            assert got.shape == want.shape
+            assert np.array_equal(got, want), f"page {i}: {(got != want).sum()} pixels differ"
+        assert not doc.classify().is_text
+
+
+def test_ccitt_damaged_data_never_crashes():
+    pdf = bytearray(synth.make_scanned_pdf([_bilevel(5, 200, 160)], codec="ccitt", dpi=72))
+    start = pdf.index(b"stream\n") + 7
+    rng = np.random.default_rng(0)
+    for trial in range(40):
+        bad = bytearray(pdf)
+        for _ in range(1 + trial % 5):
+            bad[start + int(rng.integers(0, 300))] = int(rng.integers(0, 256))
+        try:
+            with reader.PdfDocument(bytes(bad)) as doc:
+                im = doc.main_image(0)
+                if im is not None and im.codec == reader.CODEC_RAW:
+                    out = doc.decode_image(im)
+                    assert out.shape == (200, 160)
+        except reader.PdfError:
+            pass
