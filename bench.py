@@ -57,6 +57,7 @@ def parse_args():
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--cpu", action="store_true", help="debug: tiny model on CPU")
     ap.add_argument("--stage-times", action="store_true")
+    ap.add_argument("--slots", type=int, default=0, help="pipeline streams (0: engine default)")
     ap.add_argument("--weights", default=str(ROOT / "weights"), help="directory with dbnet/crnn .safetensors")
     ap.add_argument("--random-init", action="store_true", help="ignore trained weights")
     ap.add_argument("--recognizer", choices=["crnn", "trocr"], default="crnn",
@@ -86,6 +87,8 @@ def main():
     from distributed_llms_amd.runtime.document import DocumentPipeline
 
     cfg = EngineConfig(max_batch_pages=args.batch_pages, use_hip_graphs=not args.no_graphs)
+    if args.slots > 0:
+        cfg.pipeline_slots = args.slots
     det = rec = None
     size = synth.A4_300DPI
     if not use_gpu:

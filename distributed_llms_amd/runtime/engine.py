@@ -105,6 +105,7 @@ class EngineConfig:
     vertical_ratio: float = 1.5
     use_hip_graphs: bool = True
     graph_max_crops: int = 128
+    pipeline_slots: int = 2           # HIP streams the batches rotate over (det of k+1 overlaps rec of k, ...)
     trocr_batch: int = 256            # crops per encoder / decoder pass of the transformer recognizer
     trocr_max_tokens: int = 64        # greedy decode length (the decoder runs a fixed number of steps)
     db: dbpost.DBPostConfig = field(default_factory=dbpost.DBPostConfig)
@@ -152,7 +153,8 @@ class OcrEngine:
         self._trocr_event = None      # the decoder's static graph state is shared by both pipeline slots
         self.timer = StageTimer()
         self._ws: Dict[Tuple[int, int, int], dbpost.DBPostWorkspace] = {}
-        self._streams = [torch.cuda.Stream(self.device) for _ in range(2)] if self.on_gpu else [None, None]
+        ns = max(2, int(self.cfg.pipeline_slots))
+        self._streams = [torch.cuda.Stream(self.device) for _ in range(ns)] if self.on_gpu else [None] * ns
         self._graphs: Dict[Tuple[int, int, int], "_RecGraph"] = {}
         cs = getattr(self.rec, "charset", "")
         self._lut = None
@@ -517,7 +519,7 @@ class OcrEngine:
                 continue
             t0 = time.perf_counter()
             det_q.append(self._submit_det(batch, slot))
-            slot ^= 1
+            slot = (slot + 1) % len(self._streams)
             self.timer.add("submit_det", time.perf_counter() - t0)
             if len(det_q) > 1:
                 rec_q.append(self._advance(det_q.pop(0)))
