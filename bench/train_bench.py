@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--width", type=int, default=512)
-    ap.add_argument("--mode", default="allreduce", choices=["allreduce", "rs_ag"])
+    ap.add_argument("--mode", default="allreduce", choices=["allreduce", "rs_ag", "direct"])
     ap.add_argument("--bucket-mb", type=float, default=64.0)
     ap.add_argument("--cpu", action="store_true")
     ap.add_argument("--distinct", type=int, default=4, help="pre-rendered batches cycled through")

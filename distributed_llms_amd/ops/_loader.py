@@ -93,4 +93,12 @@ def _declare(l: ctypes.CDLL) -> None:
     sig("dlamd_adamw", [vp, vp, vp, vp, vp, ll, f, f, f, f, f, f, f, vp, vp])
     sig("dlamd_sumsq", [vp, ll, vp, vp])
     sig("dlamd_jpeg_decode", [vp, i, i, ll, vp])
+    sig("dlamd_dar_create", [i, i, ll, i, vp])
+    sig("dlamd_dar_export", [vp, vp])
+    sig("dlamd_dar_import", [vp, i, vp])
+    sig("dlamd_dar_info", [vp, i])
+    sig("dlamd_dar_status", [vp])
+    sig("dlamd_dar_set_spin_limit", [vp, ll])
+    sig("dlamd_dar_allreduce", [vp, vp, vp, ll, i, f, i, vp])
+    sig("dlamd_dar_destroy", [vp])
     sig("dlamd_embed_rows", [vp, vp, vp, vp, vp, ll, i, i, i, i, f, vp])

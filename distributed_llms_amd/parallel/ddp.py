@@ -11,7 +11,11 @@ Consequences taken here:
 * ``mode="rs_ag"`` splits the all-reduce into reduce-scatter + all-gather, which maps
   to the direct (all-links) algorithm on a fully connected mesh and lets the optimizer
   run on a 1/N shard between the two halves (``ShardedFlatOptimizer``);
-  ``mode="allreduce"`` leaves the algorithm choice to RCCL.
+  ``mode="allreduce"`` leaves the algorithm choice to RCCL;
+* ``mode="direct"`` runs the in-repo two-phase all-links kernel over HIP IPC peer buffers
+  (parallel/direct.py, csrc/kernels/direct_allreduce.hip) on a side stream, with the 1/N
+  averaging folded into the kernel; single node, 2..8 ranks, GPU only (CPU groups and
+  larger worlds quietly use ``allreduce``).
 
 Parameters and gradients are *views* into the flat buffers, so the fused AdamW kernel
 (ops/optim.py) updates a whole bucket in one launch and no copy-in/copy-out happens.
@@ -103,13 +107,24 @@ class BucketedDDP:
 
     def __init__(self, module: torch.nn.Module, bucket_mb: float = 64.0, mode: str = "allreduce",
                  group: Optional[dist.ProcessGroup] = None, broadcast_params: bool = True):
-        assert mode in ("allreduce", "rs_ag")
+        assert mode in ("allreduce", "rs_ag", "direct")
         self.module = module
         self.mode = mode
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.flat = FlatBuckets(module.parameters(), int(bucket_mb * (1 << 20)), pad_to=max(1, self.world) * 4)
+        self.flat = FlatBuckets(module.parameters(), int(bucket_mb * (1 << 20)), pad_to=max(1, self.world) * 8)
+        self._direct = None
+        self._comm_stream = None
+        if mode == "direct":
+            if self.flat.device.type == "cuda" and 2 <= self.world <= 8:
+                from .direct import DirectAllReduce
+
+                big = max(b.flat_grad.numel() * b.flat_grad.element_size() for b in self.flat.buckets)
+                self._direct = DirectAllReduce(big, group=group, device=self.flat.device)
+                self._comm_stream = torch.cuda.Stream(self.flat.device)
+            else:
+                self.mode = "allreduce"
         self.comm_bytes = 0
         self.comm_calls = 0
         if self.world > 1 and broadcast_params:
@@ -144,6 +159,13 @@ class BucketedDDP:
             self._launch(b)
 
     def _launch(self, b: Bucket) -> None:
+        if self.mode == "direct":
+            self._comm_stream.wait_stream(torch.cuda.current_stream(self.flat.device))
+            with torch.cuda.stream(self._comm_stream):
+                self._direct.all_reduce_(b.flat_grad, scale=1.0 / self.world)
+            self.comm_bytes += b.flat_grad.numel() * b.flat_grad.element_size()
+            self.comm_calls += 1
+            return
         b.flat_grad.div_(self.world)
         if self.mode == "allreduce":
             b.handle = dist.all_reduce(b.flat_grad, group=self.group, async_op=True)
@@ -165,6 +187,8 @@ class BucketedDDP:
                     self._launch(b)
                 if b.handle is not None:
                     b.handle.wait()
+            if self._direct is not None:
+                torch.cuda.current_stream(self.flat.device).wait_stream(self._comm_stream)
         self._reset()
 
     def shard_range(self, b: Bucket):

@@ -25,7 +25,7 @@ def main(argv=None) -> int:
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--lr", type=float, default=1e-3)
-    ap.add_argument("--mode", default="allreduce", choices=["allreduce", "rs_ag"])
+    ap.add_argument("--mode", default="allreduce", choices=["allreduce", "rs_ag", "direct"])
     ap.add_argument("--bucket-mb", type=float, default=64.0)
     ap.add_argument("--out", default="weights")
     ap.add_argument("--ckpt-every", type=int, default=500)

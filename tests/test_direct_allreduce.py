@@ -1,0 +1,158 @@
+"""Direct all-reduce over HIP IPC peer buffers (parallel/direct.py, csrc/kernels/direct_allreduce.hip).
+
+The GPU tests run N ranks as N processes that all use cuda:0 (the test box has one GPU): buffers still
+travel through hipIpcGetMemHandle / hipIpcOpenMemHandle and the kernels of different processes
+synchronise through flags in each other's memory, exactly as across xGMI.  The process group that
+carries the handles is gloo (RCCL refuses two ranks on one device).  Oracle: the same sum in plain
+PyTorch fp32, in rank order.
+"""
+import os
+import socket
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle(parts, scale, dtype):
+    acc = torch.zeros_like(parts[0], dtype=torch.float32)
+    for p in parts:
+        acc += p.float()
+    return (acc * scale).to(dtype)
+
+
+def _rank_main(rank, world, port, out_dir, starve):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from distributed_llms_amd.parallel.direct import DirectAllReduce
+
+    ar = DirectAllReduce(max_bytes=8 << 20, blocks=32)
+    res = {"uncached_flags": ar.flags_uncached, "cases": []}
+    g = torch.Generator().manual_seed(1234)
+    cases = [(torch.float32, 4096, "one_shot"), (torch.float32, 4096, "two_shot"), (torch.bfloat16, 8, "auto"),
+             (torch.bfloat16, 1 << 20, "one_shot"), (torch.bfloat16, (1 << 20) + 8 * 37, "two_shot"),
+             (torch.float32, (2 << 20) - 4, "auto"), (torch.bfloat16, 4 << 20, "auto")]
+    for rep in range(3):                       # repeats reuse both slots and both flag phases
+        for dtype, n, algo in cases:
+            parts = [(torch.randn(n, generator=g) * (p + 1)).to(dtype) for p in range(world)]   # same stream on every rank
+            x = parts[rank].cuda()
+            scale = 1.0 / world if rep == 1 else 1.0
+            y = ar.all_reduce_(x, scale=scale, algo=algo)
+            torch.cuda.synchronize()
+            want = _oracle(parts, scale, dtype)
+            got = y.cpu()
+            res["cases"].append((str(dtype), n, algo, rep, bool(torch.equal(got, want)),
+                                 float((got.float() - want.float()).abs().max())))
+    # out-of-place on a side stream, ordered by events like the DDP hook does
+    st = torch.cuda.Stream()
+    parts = [torch.full((4096,), float(p + 1)) for p in range(world)]
+    x, out = parts[rank].cuda(), torch.empty(4096, device="cuda")
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        ar.all_reduce_(x, out=out)
+    torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+    res["side_stream"] = bool(torch.equal(out.cpu(), _oracle(parts, 1.0, torch.float32)))
+    res["status"] = ar.status()
+    if starve:
+        # rank 1 skips a call: rank 0's bounded spin must run out, set the status word and let the grid drain
+        dist.barrier()
+        if rank == 0:
+            ar.set_spin_limit(20000)
+            ar.all_reduce_(torch.ones(4096, device="cuda"))
+            torch.cuda.synchronize()
+            res["starved_status"] = ar.status()
+        dist.barrier()
+    torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _spawn(world, starve=False):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_rank_main, args=(world, _free_port(), d, starve), nprocs=world, join=True)
+        return [torch.load(os.path.join(d, f"r{r}.pt"), weights_only=True) for r in range(world)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4, 3])
+def test_direct_allreduce_matches_fp32_oracle(world):
+    res = _spawn(world)
+    for r in res:
+        bad = [c for c in r["cases"] if not c[4]]
+        assert not bad, bad[:4]
+        assert r["side_stream"] and r["status"] == 0
+    assert len(res[0]["cases"]) == 21
+
+
+@pytest.mark.gpu
+def test_direct_allreduce_bounded_spin_reports_missing_peer():
+    res = _spawn(2, starve=True)
+    assert res[0]["status"] == 0 and res[0]["starved_status"] == 1
+
+
+def _ddp_rank(rank, world, port, out_dir, mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from distributed_llms_amd.parallel.ddp import BucketedDDP
+
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.ReLU(), torch.nn.Linear(256, 256), torch.nn.ReLU(),
+                              torch.nn.Linear(256, 8)).cuda()
+    ddp = BucketedDDP(net, bucket_mb=0.1, mode=mode)
+    assert len(ddp.flat.buckets) > 1
+    g = torch.Generator().manual_seed(7 + rank)
+    for _ in range(3):
+        ddp.zero_grad()
+        x = torch.randn(32, 64, generator=g).cuda()
+        net(x).square().mean().backward()
+        ddp.finish_backward()
+        with torch.no_grad():
+            for b in ddp.flat.buckets:
+                b.flat_param.add_(b.flat_grad, alpha=-0.1)
+    torch.cuda.synchronize()
+    torch.save({"flat": torch.cat([b.flat_param for b in ddp.flat.buckets]).cpu(), "mode": ddp.mode,
+                "status": ddp._direct.status() if ddp._direct is not None else 0}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_bucketed_ddp_direct_mode_equals_allreduce_mode():
+    out = {}
+    for mode in ("direct", "allreduce"):
+        with tempfile.TemporaryDirectory() as d:
+            mp.spawn(_ddp_rank, args=(2, _free_port(), d, mode), nprocs=2, join=True)
+            out[mode] = [torch.load(os.path.join(d, f"r{r}.pt"), weights_only=True) for r in range(2)]
+    assert out["direct"][0]["mode"] == "direct" and out["direct"][0]["status"] == 0
+    assert torch.equal(out["direct"][0]["flat"], out["direct"][1]["flat"]), "ranks must stay bitwise in step"
+    torch.testing.assert_close(out["direct"][0]["flat"], out["allreduce"][0]["flat"], rtol=1e-5, atol=1e-6)
+
+
+def test_direct_mode_falls_back_on_cpu_groups():
+    """CPU process groups have no IPC buffers: mode='direct' must quietly become 'allreduce'."""
+    from distributed_llms_amd.parallel.ddp import BucketedDDP
+
+    net = torch.nn.Linear(8, 8)
+    ddp = BucketedDDP(net, mode="direct")
+    assert ddp.mode == "allreduce" and ddp._direct is None
+
+
+def test_supported_predicate():
+    from distributed_llms_amd.parallel.direct import supported
+
+    assert not supported(torch.zeros(8))                      # CPU tensor
