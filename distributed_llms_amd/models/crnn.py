@@ -55,6 +55,7 @@ class CRNN(nn.Module):
         self.rnn2 = nn.LSTM(2 * hidden, hidden, batch_first=True, bidirectional=True)
         self.fc = nn.Linear(2 * hidden, self.num_classes)
         self._packed = None
+        self.fused_train_lstm = hidden in (64, 128, 256)   # device tensors: HIP recurrence kernels in forward()
 
     @staticmethod
     def time_steps(width: int) -> int:
@@ -71,7 +72,15 @@ class CRNN(nn.Module):
         for c in self.convs:
             y = c(y)
         y = y.squeeze(2).transpose(1, 2)  # [N, T, C]
-        if lens is not None:
+        if y.is_cuda and self.fused_train_lstm:
+            # persistent HIP recurrences (ops/lstm_train.py): 2 launches per layer and direction pair instead of
+            # one GEMM + cell kernel per time step
+            from ..ops.lstm_train import bilstm_train
+
+            ld = None if lens is None else lens.to(y.device, torch.int32)
+            y = bilstm_train(y, self.rnn1, ld)
+            y = bilstm_train(y, self.rnn2, ld)
+        elif lens is not None:
             packed = nn.utils.rnn.pack_padded_sequence(y, lens.cpu().long(), batch_first=True, enforce_sorted=False)
             o, _ = self.rnn1(packed)
             o, _ = self.rnn2(o)

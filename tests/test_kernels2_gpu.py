@@ -263,3 +263,43 @@ def test_trained_weights_read_an_unseen_page():
         cer = _edit_distance(got, want) / max(len(want), 1)
         assert cer < 0.10, (cer, got[:200], want[:200])
     assert truths[0].texts[0].split()[0] in doc.text
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,N,T,I", [(256, 37, 24, 128), (64, 16, 9, 64), (128, 5, 17, 96)])
+def test_lstm_train_kernels_match_packed_nn_lstm(H, N, T, I):
+    """Forward output and every gradient of ops/lstm_train.bilstm_train vs nn.LSTM (fp32, packed sequence)."""
+    from distributed_llms_amd.ops.lstm_train import bilstm_train
+
+    torch.manual_seed(3)
+    m = torch.nn.LSTM(I, H, batch_first=True, bidirectional=True).cuda()
+    x = torch.randn(N, T, I, device="cuda")
+    lens = torch.randint(1, T + 1, (N,))
+    lens[0] = T
+    go = torch.randn(N, T, 2 * H, device="cuda")
+
+    xr = x.clone().requires_grad_(True)
+    packed = torch.nn.utils.rnn.pack_padded_sequence(xr, lens, batch_first=True, enforce_sorted=False)
+    o, _ = m(packed)
+    want, _ = torch.nn.utils.rnn.pad_packed_sequence(o, batch_first=True, total_length=T)
+    (want * go).sum().backward()
+    ref = {k: p.grad.clone() for k, p in m.named_parameters()}
+    ref_dx = xr.grad.clone()
+    m.zero_grad()
+
+    xk = x.clone().requires_grad_(True)
+    got = bilstm_train(xk, m, lens.cuda().int())
+    (got.float() * go).sum().backward()
+    torch.cuda.synchronize()
+    assert got.shape == want.shape and got.dtype == torch.bfloat16
+    assert torch.allclose(got.float(), want, atol=3e-2, rtol=3e-2), float((got.float() - want).abs().max())
+    for n in range(N):
+        assert float(got[n, int(lens[n]):].abs().sum()) == 0.0
+
+    def rel(a, b):
+        return float((a - b).norm() / (b.norm() + 1e-6))
+
+    assert rel(xk.grad, ref_dx) < 3e-2, rel(xk.grad, ref_dx)
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        assert rel(p.grad, ref[k]) < 3e-2, (k, rel(p.grad, ref[k]))
