@@ -80,6 +80,8 @@ class CRNN(nn.Module):
             ld = None if lens is None else lens.to(y.device, torch.int32)
             y = bilstm_train(y, self.rnn1, ld)
             y = bilstm_train(y, self.rnn2, ld)
+            if not torch.is_autocast_enabled():
+                y = y.to(self.fc.weight.dtype)
         elif lens is not None:
             packed = nn.utils.rnn.pack_padded_sequence(y, lens.cpu().long(), batch_first=True, enforce_sorted=False)
             o, _ = self.rnn1(packed)
