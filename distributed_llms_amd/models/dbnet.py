@@ -56,6 +56,8 @@ class DBNet(nn.Module):
         self.head1 = ConvBNAct(inner, q, 3, 1, act="relu")
         self.head2 = Deconv2x2(q, q, act="relu", bn=True)
         self.head3 = Deconv2x2(q, 1, act="sigmoid", bn=False)
+        self.fuse_head_tail = True      # device inference: ops/conv.db_head_fused when q == 64
+        self._head_tail = None
         self.inner, self.q = inner, q
         # prior-probability init (focal-loss style): near-zero last-layer weights + bias -2.2 make an untrained
         # network predict p ~ 0.1 everywhere, i.e. an empty mask - no hallucinated boxes before training
@@ -109,6 +111,17 @@ class DBNet(nn.Module):
         self.p3.infer(o3, out=concat_buf, out_coff=2 * q, out_mode=C.OUT_REPLICATE, out_f=2)
         self.p2.infer(o2, out=concat_buf, out_coff=3 * q)
         h = self.head1.infer(concat_buf)
+        if self.fuse_head_tail and h.is_cuda and q == 64 and h.shape[2] % 2 == 0:
+            # both deconvs + sigmoid + threshold in one kernel: the half-resolution 64-channel map never hits HBM
+            if self._head_tail is None:
+                if self.head2._packed is None:
+                    self.head2.prepare()
+                if self.head3._packed is None:
+                    self.head3.prepare()
+                (w2, b2), (w3, b3) = self.head2._packed, self.head3._packed
+                self._head_tail = (w2.reshape(256, 64).contiguous(), b2.float().contiguous(),
+                                   C.db_head_a2_fragments(w3.reshape(4, 64)), b3.float().contiguous())
+            return C.db_head_fused(h.contiguous(), *self._head_tail, thr=self.bin_thresh)
         h = self.head2.infer(h)
         prob, mask = self.head3.infer(h, prob_thr=self.bin_thresh)
         return prob, mask
@@ -116,7 +129,17 @@ class DBNet(nn.Module):
     def prepare(self) -> "DBNet":
         self.eval()
         prepare_all(self)
+        self._head_tail = None
         return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            self._head_tail = None
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self._head_tail = None
+        return super()._apply(fn, *a, **k)
 
     def flops_per_page(self, H: int, W: int) -> float:
         """Dense conv FLOPs (2*MACs) of one forward at input H x W."""

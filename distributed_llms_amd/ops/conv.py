@@ -53,6 +53,10 @@ def weight_fragments(w: torch.Tensor) -> torch.Tensor:
     return f
 
 
+# bench/conv_layer_breakdown.py sets this to a list: every launch appends (shape key, start event, end event)
+PROFILE_SINK = None
+
+
 def _pair(v: IntPair) -> Tuple[int, int]:
     return (v, v) if isinstance(v, int) else (int(v[0]), int(v[1]))
 
@@ -204,6 +208,10 @@ def conv2d_nhwc(
     if USE_WEIGHT_FRAGMENTS:
         frag = wfrag if wfrag is not None else weight_fragments(w)
         assert frag.is_contiguous() and frag.dtype == torch.bfloat16 and frag.dim() == 4 and frag.shape[2:] == (64, 8)
+    prof = PROFILE_SINK
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = _loader.lib().dlamd_conv2d(
         _loader.ptr(x), _loader.ptr(w), _loader.ptr(bias), _loader.ptr(res if res_mode != RES_NONE else None),
         _loader.ptr(y), _loader.ptr(mask),
@@ -214,6 +222,9 @@ def conv2d_nhwc(
         _loader.stream_ptr(),
     )
     _loader.check(rc, "dlamd_conv2d")
+    if prof is not None:
+        e1.record()
+        prof.append(((B * Ho * Wo, Cout, kh * kw * Cin, f"{kh}x{kw} s{sh}{sw} {act} om{out_mode} rm{res_mode}"), e0, e1))
     if out_mode == OUT_PROB:
         return y, mask
     return y
@@ -269,3 +280,41 @@ def linear_bf16(
         out_dtype=out_dtype, wfrag=weight_fragments(w) if (x.is_cuda and USE_WEIGHT_FRAGMENTS) else None,
     )
     return y.reshape(*lead, N)
+
+
+def db_head_a2_fragments(w3: torch.Tensor, cmid: int = 64) -> torch.Tensor:
+    """MFMA A fragments [8, 64, 8] of the fused DB head's second GEMM (csrc/kernels/db_head.hip).
+
+    ``w3``: the last deconv as GEMM rows [4 (r = dy, dx), cmid].  A2[(q, r), (g, c')] = [q == g] * w3[r, c'] over the
+    256 rows (g, c') of the first deconv; its K order is permuted so that K-step s, lane group fq, element j is row
+    ``(2s + j // 4) * 16 + 4 fq + j % 4`` - the accumulator values a lane holds after the first GEMM."""
+    assert cmid == 64 and tuple(w3.shape[-1:]) == (cmid,) and w3.numel() == 4 * cmid
+    w3 = w3.reshape(4, cmid).float()
+    a2 = torch.zeros(16, 4 * cmid, device=w3.device)
+    for q in range(4):
+        a2[4 * q : 4 * q + 4, q * cmid : (q + 1) * cmid] = w3
+    lane = torch.arange(64, device=w3.device)
+    row, fq = lane % 16, lane // 16
+    s = torch.arange(8, device=w3.device)[:, None, None]
+    j = torch.arange(8, device=w3.device)[None, None, :]
+    n = (2 * s + j // 4) * 16 + 4 * fq[None, :, None] + j % 4                 # [8, 64, 8]
+    return a2[row[None, :, None].expand_as(n), n].to(torch.bfloat16).contiguous()
+
+
+def db_head_fused(h: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, a2frag: torch.Tensor, b3: torch.Tensor,
+                  thr: float = 0.3) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Deconv(64->64, ReLU) + deconv(64->1) + sigmoid + threshold in one kernel.  h [B,Hq,Wq,64] bf16 ->
+    (prob [B,4Hq,4Wq] bf16, mask uint8); same arithmetic as the two ``conv2d_nhwc`` launches it replaces."""
+    assert h.is_cuda and h.dtype == torch.bfloat16 and h.is_contiguous() and h.dim() == 4 and h.shape[3] == 64
+    B, Hq, Wq, _ = h.shape
+    assert Wq % 2 == 0, "fused DB head needs an even quarter-resolution width"
+    assert w2.dtype == torch.bfloat16 and w2.is_contiguous() and w2.numel() == 256 * 64
+    assert b2.dtype == torch.float32 and b2.numel() == 256 and b3.dtype == torch.float32 and b3.numel() == 4
+    assert a2frag.dtype == torch.bfloat16 and a2frag.is_contiguous() and tuple(a2frag.shape) == (8, 64, 8)
+    prob = torch.empty((B, 4 * Hq, 4 * Wq), dtype=torch.bfloat16, device=h.device)
+    mask = torch.empty((B, 4 * Hq, 4 * Wq), dtype=torch.uint8, device=h.device)
+    rc = _loader.lib().dlamd_db_head_fused(_loader.ptr(h), _loader.ptr(w2), _loader.ptr(b2), _loader.ptr(a2frag),
+                                           _loader.ptr(b3), _loader.ptr(prob), _loader.ptr(mask), B, Hq, Wq, float(thr),
+                                           _loader.stream_ptr())
+    _loader.check(rc, "dlamd_db_head_fused")
+    return prob, mask

@@ -303,3 +303,38 @@ def test_lstm_train_kernels_match_packed_nn_lstm(H, N, T, I):
     for k, p in m.named_parameters():
         assert p.grad is not None, k
         assert rel(p.grad, ref[k]) < 3e-2, (k, rel(p.grad, ref[k]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 12, 38), (1, 5, 16), (3, 7, 2)])
+def test_db_head_fused_matches_the_two_deconv_launches(shape):
+    """ops/conv.db_head_fused (csrc/kernels/db_head.hip) vs head2 + head3 through conv2d_nhwc and vs the fp32 module."""
+    from distributed_llms_amd.models.dbnet import DBNet
+    from distributed_llms_amd.ops import conv as C
+
+    B, Hq, Wq = shape
+    torch.manual_seed(5)
+    net = DBNet().cuda().eval()
+    with torch.no_grad():
+        net.head3.deconv.weight.mul_(300.0)         # spread the probabilities over (0, 1)
+        net.head3.deconv.bias.fill_(0.0)
+        for m in (net.head2.bn,):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    net.prepare()
+    h = (torch.randn(B, Hq, Wq, 64, device="cuda") * 0.7).to(torch.bfloat16)
+    mid = net.head2.infer(h)
+    p_ref, m_ref = net.head3.infer(mid, prob_thr=0.5)
+    (w2, b2), (w3, b3) = net.head2._packed, net.head3._packed
+    p_f, m_f = C.db_head_fused(h, w2.reshape(256, 64).contiguous(), b2.float().contiguous(),
+                               C.db_head_a2_fragments(w3.reshape(4, 64)), b3.float().contiguous(), thr=0.5)
+    torch.cuda.synchronize()
+    assert p_f.shape == p_ref.shape == (B, 4 * Hq, 4 * Wq) and m_f.dtype == torch.uint8
+    assert float(p_ref.float().std()) > 0.05
+    assert float((p_f.float() - p_ref.float()).abs().max()) <= 1.0 / 64       # one bf16 step near 1.0 is 1/256
+    assert float((m_f != m_ref).float().mean()) < 5e-3 and 0.1 < float(m_ref.float().mean()) < 0.9
+    assert torch.equal(m_f, (p_f.float() > 0.5).to(torch.uint8)), "mask must be the threshold of the stored probability"
+    # fp32 module path: ConvTranspose2d + BN + ReLU + ConvTranspose2d + sigmoid
+    with torch.no_grad():
+        want = net.head3(net.head2(h.float().permute(0, 3, 1, 2)))[:, 0]
+    assert float((p_f.float() - want).abs().max()) < 0.03
