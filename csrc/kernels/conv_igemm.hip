@@ -903,9 +903,10 @@ static int dispatch(ConvArgs& a, hipStream_t stream, int cfg) {
   }
 }
 
-// conv_stem.hip: 3x3 / stride 2 / pad 1 / Cin 8 first-layer kernel
-int dlamd_conv_stem_c8s2(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Ho, int Wo, int Cout,
-                         int act, int y_cstride, int y_coff, hipStream_t stream);
+// conv_stem.hip: 3x3 / pad 1 / small-Cin first-layer kernels
+bool dlamd_conv_stem_serves(int Cin, int stride, int Cout);
+int dlamd_conv_stem(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int stride, int Ho,
+                    int Wo, int Cout, int act, int y_cstride, int y_coff, hipStream_t stream);
 
 extern "C" int dlamd_conv2d(const void* x, const void* w, const float* bias, const void* res, void* y, void* mask,
                             int B, int H, int W, int Cin, int x_cstride, int Cout, int kh, int kw, int sh, int sw,
@@ -952,13 +953,13 @@ extern "C" int dlamd_conv2d(const void* x, const void* w, const float* bias, con
   if (a.res_mode != 0 && res_cstride % 4 != 0) return -10;
   if (a.Ho <= 0 || a.Wo <= 0) return -11;
   if ((long long)a.K > 32768) return -12;
-  // First layers (RGB padded to 8 channels, 3x3 stride 2): memory-bound stencil kernel, 3 - 8x the generic path
+  // First layers (Cin 8 stride 2; Cin 32 stride 1 / 2): memory-bound stencil kernels (conv_stem.hip)
   // (cfg 9008 forces it, any other explicit cfg keeps the generic kernels for tests / sweeps)
-  const bool stem_ok = Cin == 8 && x_cstride == 8 && kh == 3 && kw == 3 && sh == 2 && sw == 2 && ph == 1 && pw == 1 &&
-                       out_mode == 0 && a.res_mode == 0 && !y_f32 && (Cout == 32 || Cout == 64) && y_cstride % 8 == 0 &&
+  const bool stem_ok = x_cstride == Cin && kh == 3 && kw == 3 && sh == sw && ph == 1 && pw == 1 && out_mode == 0 &&
+                       a.res_mode == 0 && !y_f32 && dlamd_conv_stem_serves(Cin, sh, Cout) && y_cstride % 8 == 0 &&
                        y_coff % 8 == 0;
   if (stem_ok && (cfg == 0 || cfg == 9008))
-    return dlamd_conv_stem_c8s2(x, w, bias, y, B, H, W, a.Ho, a.Wo, Cout, act, y_cstride, y_coff, stream);
+    return dlamd_conv_stem(x, w, bias, y, B, H, W, Cin, sh, a.Ho, a.Wo, Cout, act, y_cstride, y_coff, stream);
   if (cfg == 9008) return -13;
   // cfg 3xxx forces / 39xx forbids the LDS-patch 3x3 kernel (benchmarks and tests); default: use it when it applies
   const bool patch_ok = a.wfrag && kh == 3 && kw == 3 && ph == 1 && pw == 1 && sw == 1 && (sh == 1 || sh == 2) &&

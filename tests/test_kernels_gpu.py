@@ -58,16 +58,17 @@ def test_conv_matches_reference(case):
         _close(out, ref)
 
 
-@pytest.mark.parametrize("case", [(2, 48, 200, 64, "relu"), (1, 47, 131, 64, "hardswish"), (3, 17, 64, 32, "relu"),
-                                  (1, 96, 1030, 32, "none"), (2, 1, 5, 64, "relu")])
+@pytest.mark.parametrize("case", [(2, 48, 200, 8, 2, 64, "relu"), (1, 47, 131, 8, 2, 64, "hardswish"), (3, 17, 64, 8, 2, 32, "relu"),
+                                  (1, 96, 1030, 8, 2, 32, "none"), (2, 1, 5, 8, 2, 64, "relu"),
+                                  (2, 21, 150, 32, 1, 32, "relu"), (1, 8, 64, 32, 1, 32, "hardswish"), (1, 3, 7, 32, 1, 32, "none")])
 def test_conv_stem_kernel_matches_reference_and_generic_path(case):
-    """cfg 9008 = the Cin-8 / 3x3 / stride-2 first-layer kernel (csrc/kernels/conv_stem.hip); cfg 0 must pick it."""
-    B, H, W, Cout, act = case
-    x = _rand_bf16(B, H, W, 8, seed=11)
-    w = _rand_bf16(Cout, 3, 3, 8, scale=(2.0 / 72) ** 0.5, seed=12)
+    """cfg 9008 = the small-Cin 3x3 first-layer kernels (csrc/kernels/conv_stem.hip); cfg 0 must pick them."""
+    B, H, W, Cin, st, Cout, act = case
+    x = _rand_bf16(B, H, W, Cin, seed=11)
+    w = _rand_bf16(Cout, 3, 3, Cin, scale=(2.0 / (9 * Cin)) ** 0.5, seed=12)
     b = torch.randn(Cout, generator=torch.Generator().manual_seed(13)) * 0.1
-    ref = C.conv2d_nhwc_reference(x, w, b, stride=2, padding=1, act=act, out_dtype=torch.float32)
-    outs = {cfg: C.conv2d_nhwc(x.to(DEV), w.to(DEV), b.to(DEV), stride=2, padding=1, act=act, cfg=cfg) for cfg in (9008, 0, 64)}
+    ref = C.conv2d_nhwc_reference(x, w, b, stride=st, padding=1, act=act, out_dtype=torch.float32)
+    outs = {cfg: C.conv2d_nhwc(x.to(DEV), w.to(DEV), b.to(DEV), stride=st, padding=1, act=act, cfg=cfg) for cfg in (9008, 0, 64)}
     for o in outs.values():
         assert o.shape == ref.shape
         _close(o, ref)
@@ -75,11 +76,11 @@ def test_conv_stem_kernel_matches_reference_and_generic_path(case):
     # fused concat: write at a channel offset of a wider buffer, neighbours untouched
     Ho, Wo = ref.shape[1:3]
     buf = torch.full((B, Ho, Wo, Cout + 16), 7.0, dtype=torch.bfloat16, device=DEV)
-    C.conv2d_nhwc(x.to(DEV), w.to(DEV), b.to(DEV), stride=2, padding=1, act=act, out=buf, out_coff=8, cfg=9008)
+    C.conv2d_nhwc(x.to(DEV), w.to(DEV), b.to(DEV), stride=st, padding=1, act=act, out=buf, out_coff=8, cfg=9008)
     _close(buf[..., 8:8 + Cout], ref)
     assert float((buf[..., :8] - 7).abs().max()) == 0 and float((buf[..., 8 + Cout:] - 7).abs().max()) == 0
-    with pytest.raises(Exception):      # a shape the kernel does not serve must be refused, not mis-run
-        C.conv2d_nhwc(x.to(DEV), w.to(DEV), b.to(DEV), stride=1, padding=1, act=act, cfg=9008)
+    with pytest.raises(Exception):      # a shape the kernels do not serve must be refused, not mis-run
+        C.conv2d_nhwc(x.to(DEV), w.to(DEV), b.to(DEV), stride=3 - st, padding=1, act=act, cfg=9008)
 
 
 @pytest.mark.parametrize("shape", [(2, 12, 70, 64, 128, (1, 1)), (3, 12, 45, 128, 256, (2, 1)), (2, 6, 130, 256, 64, (2, 1)),
