@@ -20,12 +20,27 @@
 #define MAXC_DEFAULT 4096
 
 // Page-local indices are used inside parent[] (index within the page).
-__global__ void ccl_init_local_kernel(const uint8_t* __restrict__ mask, int* __restrict__ parent, int hw, int B) {
+// Every foreground pixel starts under the first pixel of its horizontal run inside its 64-pixel wave segment
+// (segments are 64 consecutive flattened positions; a run never continues across a row start).  One ballot per
+// wave pre-merges what would otherwise be ~one atomic union per pixel: text blobs are wide, so this removes almost
+// all horizontal unions and keeps the union-find trees shallow.
+__global__ void ccl_init_local_kernel(const uint8_t* __restrict__ mask, int* __restrict__ parent, int hw, int B, int W) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   int b = blockIdx.y;
-  if (p >= hw) return;
-  long long g = (long long)b * hw + p;
-  parent[g] = mask[g] ? p : -1;
+  const bool in = p < hw;
+  long long g = (long long)b * hw + (in ? p : 0);
+  const bool fg = in && mask[g] != 0;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long fgm = __ballot(fg);
+  const unsigned long long rowstart = __ballot(in && (p % W) == 0);
+  const unsigned long long starts = fgm & (~(fgm << 1) | rowstart);
+  if (!in) return;
+  int par = -1;
+  if (fg) {
+    const unsigned long long below = starts & (~0ull >> (63 - lane));     // run starts at lanes <= lane
+    par = p - (lane - (63 - __builtin_clzll(below)));
+  }
+  parent[g] = par;
 }
 
 __device__ __forceinline__ int uf_find(int* parent, int x) {
@@ -60,10 +75,13 @@ __global__ void ccl_merge_kernel(const uint8_t* __restrict__ mask, int* __restri
   int* parent = parent_all + base;
   int p = y * W + x;
   if (!m[p]) return;
-  if (x > 0 && m[p - 1]) uf_union(parent, p, p - 1);
+  // horizontal: runs were pre-merged inside 64-pixel segments (ccl_init_local_kernel); only segment seams remain
+  if (x > 0 && (p & 63) == 0 && m[p - 1]) uf_union(parent, p, p - 1);
   if (y > 0) {
-    if (m[p - W]) uf_union(parent, p, p - W);
-    else {
+    if (m[p - W]) {
+      // vertical: one union per overlap of two runs (its leftmost pixel), the rest follows from the rows' own runs
+      if (x == 0 || !m[p - 1] || !m[p - W - 1]) uf_union(parent, p, p - W);
+    } else {
       // only needed when the pixel straight above is background
       if (x > 0 && m[p - W - 1]) uf_union(parent, p, p - W - 1);
       if (x + 1 < W && m[p - W + 1]) uf_union(parent, p, p - W + 1);
@@ -244,7 +262,7 @@ extern "C" int dlamd_db_postprocess(const void* mask, const void* prob, void* pa
     hipLaunchKernelGGL(stats_init_kernel, dim3(nb), dim3(256), 0, stream, (int*)stats, (int*)ncomp, (int*)nbox, n, B);
   }
   hipLaunchKernelGGL(ccl_init_local_kernel, dim3((hw + 255) / 256, B), dim3(256), 0, stream, (const uint8_t*)mask,
-                     (int*)parent, hw, B);
+                     (int*)parent, hw, B, W);
   dim3 grid((W + 63) / 64, (H + 3) / 4, B);
   hipLaunchKernelGGL(ccl_merge_kernel, grid, dim3(256), 0, stream, (const uint8_t*)mask, (int*)parent, H, W);
   hipLaunchKernelGGL(ccl_assign_kernel, grid, dim3(256), 0, stream, (int*)parent, (int*)comp_id, (int*)ncomp, H, W,

@@ -268,6 +268,33 @@ def test_db_postprocess_random_noise_components():
         np.testing.assert_allclose(os_[:, 5], rs[:, 5])
 
 
+@pytest.mark.parametrize("W,thr", [(100, 0.55), (100, 0.42), (72, 0.5), (64, 0.45), (200, 0.47)])
+def test_db_postprocess_row_wrap_and_segment_seams(W, thr):
+    """Widths that are not a multiple of the 64-pixel wave segment: runs must not continue across a row start, runs
+    that cross a segment seam must be joined, and dense masks build large components out of many run overlaps."""
+    g = torch.Generator().manual_seed(W)
+    H = 57
+    prob = torch.rand(2, H, W, generator=g)
+    prob[0, 10, W - 7:] = 0.99          # ends at the right border ...
+    prob[0, 11, :5] = 0.99              # ... and the next row starts at the left border: different components
+    prob[0, 9, :] = 0.0
+    prob[0, 12, :] = 0.0
+    prob[0, 11, 5:12] = 0.0
+    prob[0, 10, W - 14:W - 7] = 0.0
+    prob[1, 30, :] = 0.99               # a full-width run crosses every seam
+    prob = prob.to(torch.bfloat16)
+    mask = (prob.float() > thr).to(torch.uint8)
+    cfg = dbpost.DBPostConfig(box_thresh=0.0, min_size=1, max_components=8192, max_boxes=8192)
+    ref = dbpost.db_postprocess(prob, mask, cfg)
+    out = dbpost.db_postprocess(prob.to(DEV), mask.to(DEV), cfg)
+    for r, o in zip(ref, out):
+        assert r.shape == o.shape
+        rs = r[np.lexsort(r[:, :4].T[::-1])]
+        os_ = o[np.lexsort(o[:, :4].T[::-1])]
+        np.testing.assert_allclose(os_[:, :4], rs[:, :4], atol=1e-3)
+        np.testing.assert_allclose(os_[:, 5], rs[:, 5])
+
+
 @pytest.mark.parametrize("V,dtype", [(97, torch.bfloat16), (6624, torch.bfloat16), (50, torch.float32)])
 def test_ctc_greedy_decode(V, dtype):
     g = torch.Generator().manual_seed(0)
