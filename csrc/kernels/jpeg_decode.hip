@@ -19,6 +19,9 @@
 // thread pool instead (ops/jpeg.py).
 #include "common.h"
 
+#include <stdlib.h>
+
+#define JPEG_DEFAULT_SPREAD 1
 #define JPEG_LUT_BITS 10
 #define JPEG_LUT_SIZE (1 << JPEG_LUT_BITS)
 
@@ -117,19 +120,23 @@ __device__ __forceinline__ int receive_extend(BitReader& br, int s) {
   return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
 }
 
-__global__ __launch_bounds__(128) void jpeg_huffman_kernel(const JpegImageDesc* __restrict__ descs) {
+// `spread` = lanes per segment slot: only every spread-th lane decodes (1: all 64 lanes of a wave busy).  The decode
+// loops are data dependent, so a wave runs the union of its lanes' paths; fewer segments per wave cut that
+// divergence and spread the (few thousand) segments over more SIMDs.
+__global__ __launch_bounds__(128) void jpeg_huffman_kernel(const JpegImageDesc* __restrict__ descs, int spread) {
   __shared__ uint16_t s_lut[4][JPEG_LUT_SIZE];
   __shared__ uint16_t s_qt[64];
   __shared__ uint8_t s_zz[64];
   const JpegImageDesc d = descs[blockIdx.y];
-  if ((int)(blockIdx.x * 128) >= d.n_segments) return;
+  const int per_block = 128 / spread;
+  if ((int)(blockIdx.x * per_block) >= d.n_segments) return;
   const JpegTables* tb = d.tables;
   const int ntab = d.ncomp == 1 ? 2 : 4;
   for (int i = threadIdx.x; i < ntab * JPEG_LUT_SIZE; i += 128) (&s_lut[0][0])[i] = (&tb->lut[0][0])[i];
   if (threadIdx.x < 64) { s_qt[threadIdx.x] = tb->qt[0][threadIdx.x]; s_zz[threadIdx.x] = c_zigzag[threadIdx.x]; }
   __syncthreads();
-  const int seg = blockIdx.x * 128 + threadIdx.x;
-  if (seg >= d.n_segments) return;
+  const int seg = blockIdx.x * per_block + threadIdx.x / spread;
+  if (seg >= d.n_segments || (threadIdx.x % spread) != 0) return;
   const uint32_t start = d.seg_off[seg];
   // a segment ends 2 bytes before the next one starts (the RSTn marker) or at the end of the scan
   const uint32_t stop = (seg + 1 < d.n_segments) ? d.seg_off[seg + 1] - 2 : (uint32_t)d.scan_end;
@@ -258,8 +265,14 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const JpegImageDesc* __r
 extern "C" int dlamd_jpeg_decode(const void* descs, int n, int max_segments, long long max_blocks, hipStream_t stream) {
   if (n <= 0) return 0;
   if (n > 65535 || max_segments <= 0 || max_blocks <= 0) return -1;
-  dim3 g1((max_segments + 127) / 128, n);
-  hipLaunchKernelGGL(jpeg_huffman_kernel, g1, dim3(128), 0, stream, (const JpegImageDesc*)descs);
+  static const int spread_env = getenv("DLAMD_JPEG_SPREAD") ? atoi(getenv("DLAMD_JPEG_SPREAD")) : 0;
+  int spread = JPEG_DEFAULT_SPREAD;
+  if (spread_env == 1 || spread_env == 2 || spread_env == 4 || spread_env == 8 || spread_env == 16 || spread_env == 32 ||
+      spread_env == 64)
+    spread = spread_env;
+  const int per_block = 128 / spread;
+  dim3 g1((max_segments + per_block - 1) / per_block, n);
+  hipLaunchKernelGGL(jpeg_huffman_kernel, g1, dim3(128), 0, stream, (const JpegImageDesc*)descs, spread);
   long long gb = (max_blocks + 31) / 32;
   if (gb > 0x7fffffffLL) return -2;
   dim3 g2((unsigned)gb, n);
