@@ -156,3 +156,42 @@ def test_supported_predicate():
     from distributed_llms_amd.parallel.direct import supported
 
     assert not supported(torch.zeros(8))                      # CPU tensor
+
+
+def _trainer_rank(rank, world, port, out_dir, mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from distributed_llms_amd.models.crnn import CRNN
+    from distributed_llms_amd.parallel.comm import DistEnv
+    from distributed_llms_amd.train.trainer import CTCTrainer, TrainConfig
+
+    torch.manual_seed(0)
+    model = CRNN(hidden=64, widths=(8, 16, 16, 16, 32, 32))
+    cfg = TrainConfig(batch_size=8, width=96, lr=3e-3, vocab=3, max_chars=5, font_px=28, warmup_steps=0, bucket_mb=0.05,
+                      dp_mode=mode, amp=False)
+    tr = CTCTrainer(model, cfg, device="cuda:0", env=DistEnv(rank, world, 0, torch.device("cuda:0"), "gloo"))
+    losses = []
+    for s in range(4):
+        losses.append(tr.train_step(*tr.synthetic_batch(s)))
+        print(f"[dp-trainer {mode}] rank {rank} step {s} loss {losses[-1]:.4f}", flush=True)
+    torch.cuda.synchronize()
+    torch.save({"flat": torch.cat([b.flat_param for b in tr.ddp.flat.buckets]).cpu(), "losses": losses, "mode": tr.ddp.mode,
+                "buckets": len(tr.ddp.flat.buckets)}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_ctc_trainer_dp2_direct_allreduce_matches_process_group_allreduce():
+    """Whole training steps (fused LSTM recurrences, CTC kernel, flat AdamW) with gradients averaged by the IPC kernel."""
+    out = {}
+    for mode in ("direct", "allreduce"):
+        with tempfile.TemporaryDirectory() as d:
+            mp.spawn(_trainer_rank, args=(2, _free_port(), d, mode), nprocs=2, join=True)
+            out[mode] = [torch.load(os.path.join(d, f"r{r}.pt"), weights_only=True) for r in range(2)]
+    assert out["direct"][0]["mode"] == "direct" and out["direct"][0]["buckets"] > 1
+    assert torch.equal(out["direct"][0]["flat"], out["direct"][1]["flat"]), "ranks must hold identical parameters"
+    torch.testing.assert_close(out["direct"][0]["flat"], out["allreduce"][0]["flat"], rtol=2e-3, atol=2e-4)
+    assert all(l == l for l in out["direct"][0]["losses"])      # finite
