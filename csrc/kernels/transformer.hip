@@ -256,22 +256,32 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const bf16_t* __r
   n = min(n, 1024);
   if (tid < ATT_D) s_q[tid] = (float)q[(long long)b * q_bs + h * ATT_D + tid] * scale;
   __syncthreads();   // also orders the append above before the cache reads below (same workgroup)
-  // phase 1: threads over keys
-  float mx = ATT_NEG;
-  for (int k = tid; k < n; k += 256) {
-    const bf16_t* kr = kb + (long long)k * c_ss;
-    float acc = 0.f;
+  // phase 1: 8 lanes per key (one 16-byte chunk of the 128-byte row each), a wave covers 8 keys per load instruction:
+  // whole cache lines per request and 4 independent loads in flight per lane (the loop carries only the running max)
+  const int sub = lane & 7, kq = lane >> 3;
+  float qv[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      u32x4 raw = *reinterpret_cast<const u32x4*>(kr + c * 8);
+  for (int j = 0; j < 8; ++j) qv[j] = s_q[sub * 8 + j];
+  float mx = ATT_NEG;
+#pragma unroll 4
+  for (int k0 = wave * 8; k0 < n; k0 += 32) {
+    const int k = k0 + kq;
+    float acc = 0.f;
+    if (k < n) {
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(kb + (long long)k * c_ss + sub * 8);
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        acc += bf16_bits_to_f32(raw[w] & 0xffffu) * s_q[c * 8 + 2 * w];
-        acc += bf16_bits_to_f32(raw[w] >> 16) * s_q[c * 8 + 2 * w + 1];
+        acc += bf16_bits_to_f32(raw[w] & 0xffffu) * qv[2 * w];
+        acc += bf16_bits_to_f32(raw[w] >> 16) * qv[2 * w + 1];
       }
     }
-    s_p[k] = acc;
-    mx = fmaxf(mx, acc);
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (k < n) {
+      if (sub == 0) s_p[k] = acc;
+      mx = fmaxf(mx, acc);
+    }
   }
   mx = wave_reduce_max(mx);
   if (lane == 0) s_red[wave] = mx;
@@ -287,10 +297,31 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const bf16_t* __r
   if (lane == 0) s_red[4 + wave] = sum;
   __syncthreads();
   sum = s_red[4] + s_red[5] + s_red[6] + s_red[7];
-  // phase 2: lanes over head dims, the four waves split the keys
-  float acc = 0.f;
-  for (int k = wave; k < n; k += 4) acc += s_p[k] * (float)vb[(long long)k * c_ss + lane];
-  s_o[wave][lane] = acc;
+  // phase 2: same lane layout over V rows (16-byte loads, 8 keys per wave instruction), then fold the 8 key slots
+  float oacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int k0 = wave * 8; k0 < n; k0 += 32) {
+    const int k = k0 + kq;
+    if (k < n) {
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(vb + (long long)k * c_ss + sub * 8);
+      const float pk = s_p[k];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        oacc[2 * w] += pk * bf16_bits_to_f32(raw[w] & 0xffffu);
+        oacc[2 * w + 1] += pk * bf16_bits_to_f32(raw[w] >> 16);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    oacc[j] += __shfl_xor(oacc[j], 8, 64);
+    oacc[j] += __shfl_xor(oacc[j], 16, 64);
+    oacc[j] += __shfl_xor(oacc[j], 32, 64);
+  }
+  if (kq == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s_o[wave][sub * 8 + j] = oacc[j];
+  }
   __syncthreads();
   if (tid < ATT_D) {
     const float tot = s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid];
