@@ -875,6 +875,9 @@ static int dispatch(ConvArgs& a, hipStream_t stream, int cfg) {
       const long long t64 = (long long)((a.M + 63) / 64) * ((a.Cout + 63) / 64);
       bn = (t64 >= 160 || a.Cout < 64) ? 1064 : 2032;
       if (a.Cout < 64) bn = 2032;
+      // deep-K small-M GEMMs (decoder FFN down-projection, K = 4096): a 128-deep K tile halves the exposed load
+      // latencies of this latency-bound shape: 32.4 -> 22.8 us at M 256 (bench/small_m_probe.py); K = 1024 ties
+      if (bn == 2032 && a.K >= 2048 && a.wfrag) bn = 4032;
     }
   }
   // 1x1 layers (FPN laterals, deconv GEMMs, LSTM input projections, FC): the persistent form of the 64 x 128 tile
@@ -892,6 +895,9 @@ static int dispatch(ConvArgs& a, hipStream_t stream, int cfg) {
                  // except on 512->512 (fewer barriers, but 132 VGPRs -> 3 waves/SIMD), so auto never picks it
       if (!a.wfrag) return -14;
       return launch_impl<64, 128, 1, 4, IS_1X1, true, 128>(a, stream);
+    case 4032:   // 32 x 32 tile (small-M GEMMs: decoder steps), 128-deep K tile: half the exposed load latencies
+      if (!a.wfrag) return -14;
+      return launch_impl<32, 32, 2, 2, IS_1X1, true, 128>(a, stream);
     case 8128: return launch_persistent<64, 128, 1, 4, IS_1X1>(a, stream);   // persistent 64 x 128
     case 7256: return launch_glds<256, 2, 4, IS_1X1>(a, stream);     // 256 x 256, LDS-DMA staged, 8 waves
     case 7128: return launch_glds<128, 4, 2, IS_1X1>(a, stream);     // 256 x 128

@@ -230,6 +230,11 @@ def conv2d_nhwc(
     return y
 
 
+# plain bias-only GEMMs this wide (the decoder's 50 k-row LM head at batch 256: 89.5 us in-repo, 38.2 us hipBLASLt;
+# bench/small_m_probe.py) also go to the library
+LIBRARY_GEMM_MIN_COLS = 16384
+
+
 def linear_bf16(
     x: torch.Tensor,
     w: torch.Tensor,
@@ -251,7 +256,8 @@ def linear_bf16(
     # QKV GEMMs at 1135 against 421 / 527 for the 1x1 path of conv_igemm (bench/gemm_probe.py).  Everything
     # fused, and the small-M decode GEMMs (captured in hipGraphs), stay on the in-repo kernel.
     if (LIBRARY_GEMM_MIN_ROWS > 0 and x.is_cuda and out_dtype == torch.bfloat16 and w.is_contiguous()
-            and x.numel() // K >= LIBRARY_GEMM_MIN_ROWS
+            and (x.numel() // K >= LIBRARY_GEMM_MIN_ROWS
+                 or (N >= LIBRARY_GEMM_MIN_COLS and x.numel() // K >= 64 and act == "none" and res is None))
             and ((act == "none") or (act == "gelu" and res is None and bias is not None))):
         b16 = None
         if bias is not None:
