@@ -69,7 +69,11 @@ extern "C" int dlamd_adamw(void* p, const void* g, void* m, void* v, void* shado
 }
 
 // sum of squares of a flat fp32 buffer, accumulated into *out (caller zeroes it): global grad-norm for clipping.
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, float* __restrict__ out) {
+// Deterministic two-stage sum of squares: per-block partials, then ONE block folds them in a fixed order and adds the
+// total to *out with a plain read-modify-write (launches on a stream are ordered).  A float atomicAdd per block would
+// make the gradient norm - and through the clipping scale every parameter - depend on the order the blocks retire,
+// which lets data-parallel ranks that hold bitwise-identical gradients drift apart.
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, float* __restrict__ partial) {
   float acc = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     float x = g[i];
@@ -79,13 +83,34 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   __shared__ float s[4];
   if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, s[0] + s[1] + s[2] + s[3]);
+  if (threadIdx.x == 0) partial[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ out) {
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) acc += partial[i];
+  acc = wave_reduce_sum(acc);
+  __shared__ float s[4];
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] += (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+static float* sumsq_scratch() {
+  static float* buf[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!buf[dev] && hipMalloc((void**)&buf[dev], 1024 * sizeof(float)) != hipSuccess) buf[dev] = nullptr;
+  return buf[dev];
 }
 
 extern "C" int dlamd_sumsq(const void* g, long long n, void* out, hipStream_t stream) {
   if (n <= 0) return 0;
   long long blocks = (n + 256 * 8 - 1) / (256 * 8);
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)g, n, (float*)out);
+  float* partial = sumsq_scratch();     // one optimizer stream per process: the scratch is reused call after call
+  if (!partial) return -2;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)g, n, partial);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, stream, (const float*)partial, (int)blocks, (float*)out);
   return DLAMD_CHECK_LAUNCH();
 }

@@ -193,5 +193,11 @@ def test_ctc_trainer_dp2_direct_allreduce_matches_process_group_allreduce():
             out[mode] = [torch.load(os.path.join(d, f"r{r}.pt"), weights_only=True) for r in range(2)]
     assert out["direct"][0]["mode"] == "direct" and out["direct"][0]["buckets"] > 1
     assert torch.equal(out["direct"][0]["flat"], out["direct"][1]["flat"]), "ranks must hold identical parameters"
-    torch.testing.assert_close(out["direct"][0]["flat"], out["allreduce"][0]["flat"], rtol=2e-3, atol=2e-4)
+    # two separate runs: per-rank gradients are not bitwise reproducible (float atomics in the CTC kernel, MIOpen's
+    # algorithm choice), and Adam turns a sign flip of a near-zero gradient into an lr-sized step - compare in norm
+    a, b = out["direct"][0]["flat"], out["allreduce"][0]["flat"]
+    assert float((a - b).norm() / b.norm()) < 2e-3
+    assert float(((a - b).abs() > 2e-3).float().mean()) < 1e-3
     assert all(l == l for l in out["direct"][0]["losses"])      # finite
+    for l1, l2 in zip(out["direct"][0]["losses"], out["allreduce"][0]["losses"]):
+        assert abs(l1 - l2) < 0.05 * max(1.0, abs(l2))
