@@ -58,6 +58,9 @@ def parse_args():
     ap.add_argument("--cpu", action="store_true", help="debug: tiny model on CPU")
     ap.add_argument("--stage-times", action="store_true")
     ap.add_argument("--slots", type=int, default=0, help="pipeline streams (0: engine default)")
+    ap.add_argument("--sequential", action="store_true",
+                    help="finish each document before the next one starts (default: the K documents are queued back to back "
+                         "through one engine pipeline, as a worker with a queue of uploads runs them)")
     ap.add_argument("--weights", default=str(ROOT / "weights"), help="directory with dbnet/crnn .safetensors")
     ap.add_argument("--random-init", action="store_true", help="ignore trained weights")
     ap.add_argument("--recognizer", choices=["crnn", "trocr"], default="crnn",
@@ -149,14 +152,31 @@ def main():
 
     for _ in range(args.warmup):
         doc = run()
+    stream_docs = args.input == "pdf" and not args.sequential and args.steps > 1
+    # p50 extract latency of ONE document with nothing else in flight: measured before the timed region
+    lat = []
+    for _ in range(3 if stream_docs else 0):
+        sync()
+        tl = time.perf_counter()
+        doc = run()
+        if use_gpu:
+            torch.cuda.synchronize(device)
+        lat.append(time.perf_counter() - tl)
     engine.timer = type(engine.timer)()
     pipe.timer = type(pipe.timer)()
     sync()
     t0 = time.perf_counter()
     n_lines = 0
-    for _ in range(args.steps):
-        doc = run()
-        n_lines += sum(len(p.lines) for p in doc.pages)
+    if stream_docs:
+        # a step = one 100-page document; all K are extracted inside the timed region, queued back to back
+        docs = pipe.process_pdfs([(pdf_bytes, f"bench-{k}", priors) for k in range(args.steps)])
+        assert len(docs) == args.steps and all(len(d.pages) == args.pages_per_doc for d in docs)
+        n_lines = sum(len(p.lines) for d in docs for p in d.pages)
+        doc = docs[-1]
+    else:
+        for _ in range(args.steps):
+            doc = run()
+            n_lines += sum(len(p.lines) for p in doc.pages)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -208,7 +228,8 @@ def main():
                 "lines_per_page": round(lines_per_page, 1),
                 "batch_pages": args.batch_pages,
                 "input": args.input,
-                "p50_extract_latency_ms": round(1000.0 * dt / args.steps, 1),
+                "p50_extract_latency_ms": round(1000.0 * (sorted(lat)[len(lat) // 2] if lat else dt / args.steps), 1),
+                "documents": "queued back to back through one engine pipeline" if stream_docs else "one at a time",
                 "lines_recognized": n_lines,
                 "weights": "trained (weights/)" if trained else "random-init",
                 "cer_vs_truth": None if cer is None else round(cer, 5),

@@ -21,7 +21,7 @@ import re
 import time
 from concurrent.futures import Future, ThreadPoolExecutor
 from dataclasses import dataclass, field
-from typing import Dict, Iterator, List, Optional, Sequence
+from typing import Dict, Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -218,6 +218,69 @@ class DocumentPipeline:
             return res
         finally:
             doc.close()
+
+    def process_pdfs(self, docs: Sequence[Tuple[bytes, str, Optional[Sequence]]],
+                     force_mode: Optional[str] = None) -> List[DocumentResult]:
+        """Several documents back to back through ONE engine pipeline: ``docs`` = [(pdf_bytes, document_id,
+        layout_priors or None)].  Page batches never mix documents, but the two-stream pipeline is not drained at a
+        document boundary (detection of the next document's first batch overlaps recognition of the previous
+        document's last one) - what a worker with a queue of uploads does.  Results come back in input order."""
+        states: List[dict] = []
+        try:
+            def batches() -> Iterator[List[PageImage]]:
+                for k, (pdf_bytes, did, pri) in enumerate(docs):
+                    t0 = time.perf_counter()
+                    try:
+                        doc = reader.PdfDocument(pdf_bytes)
+                    except reader.PdfError as e:
+                        raise ExtractionError(f"cannot parse PDF {did!r}: {e}") from e
+                    cls = doc.classify()
+                    mode = force_mode or ("txt" if cls.is_text else "ocr")
+                    st = {"doc": doc, "id": did, "mode": mode, "n": doc.page_count, "skipped": [], "pages": []}
+                    states.append(st)
+                    self.timer.add("parse", time.perf_counter() - t0)
+                    if st["n"] == 0:
+                        raise ExtractionError(f"PDF {did!r} has no pages")
+                    if mode == "ocr":
+                        yield from self._page_batches(doc, list(range(st["n"])), f"{k}\x00{did}", pri, st["skipped"])
+
+            for batch_res in self.engine.process_batches(batches()):
+                for pr in batch_res:
+                    k, _, did = pr.doc_id.partition("\x00")
+                    pr.doc_id = did
+                    states[int(k)]["pages"].append(pr)
+            out: List[DocumentResult] = []
+            for st in states:
+                res = DocumentResult(st["id"], st["mode"])
+                doc = st["doc"]
+                if st["mode"] == "txt":
+                    for i in range(st["n"]):
+                        for para in doc.page_text(i).split("\n\n"):
+                            para = " ".join(x.strip() for x in para.split("\n") if x.strip())
+                            if para:
+                                res.content_list.append({"type": "text", "text": para, "page_idx": i})
+                else:
+                    pages = st["pages"]
+                    for i in st["skipped"]:
+                        pi = doc.page_info(i)
+                        pr = PageResult(st["id"], i, int(pi.width_pt), int(pi.height_pt))
+                        y = 0.0
+                        for para in doc.page_text(i, include_invisible=True).split("\n\n"):
+                            para = " ".join(x.strip() for x in para.split("\n") if x.strip())
+                            if para:
+                                pr.lines.append(TextLine((0.0, y, 1.0, y + 1.0), para, 1.0))
+                                y += 3.0
+                        pages.append(pr)
+                    pages.sort(key=lambda p: p.page_index)
+                    res.pages = pages
+                    res.content_list = build_content_list(pages)
+                res.markdown = "\n\n".join(it["text"] for it in res.content_list)
+                res.text = combine_text(res.content_list, res.markdown)
+                out.append(res)
+            return out
+        finally:
+            for st in states:
+                st["doc"].close()
 
     def process_rasters(self, images: Sequence[torch.Tensor], document_id: str = "", layout_priors=None
                         ) -> DocumentResult:

@@ -259,3 +259,35 @@ def test_ccitt_damaged_data_never_crashes():
                     assert out.shape == (200, 160)
         except reader.PdfError:
             pass
+
+
+def test_process_pdfs_streams_documents_and_matches_one_at_a_time():
+    """DocumentPipeline.process_pdfs: several documents through one engine pipeline = the same results, input order."""
+    import torch
+
+    from distributed_llms_amd.models.crnn import CRNN
+    from distributed_llms_amd.models.dbnet import DBNet
+    from distributed_llms_amd.pdf import synth
+    from distributed_llms_amd.runtime.document import DocumentPipeline
+    from distributed_llms_amd.runtime.engine import EngineConfig, OcrEngine
+
+    torch.manual_seed(0)
+    cfg = EngineConfig(max_batch_pages=2, use_hip_graphs=False)
+    cfg.det_limit_side, cfg.rec_max_width, cfg.rec_width_quantum = 160, 256, 64
+    eng = OcrEngine(torch.device("cpu"), DBNet(widths=(16, 32, 32, 64), stem=8, inner=32),
+                    CRNN(hidden=64, widths=(16, 32, 32, 32, 64, 64)), cfg, seed=1)
+    pipe = DocumentPipeline(eng)
+    docs = []
+    for k, npages in enumerate((3, 1, 2)):
+        rendered = [synth.render_page(10 * k + i, size=(248, 350), font_px=10, margin=16) for i in range(npages)]
+        pdf = synth.make_scanned_pdf([r[0] for r in rendered], codec="flate")
+        docs.append((pdf, f"doc{k}", [r[1].boxes for r in rendered]))
+    docs.append((synth.make_text_pdf(["alpha beta", "gamma"]), "txt", None))
+    many = pipe.process_pdfs(docs)
+    assert [d.document_id for d in many] == ["doc0", "doc1", "doc2", "txt"]
+    for (pdf, did, pri), got in zip(docs, many):
+        want = pipe.process_pdf(pdf, did, layout_priors=pri)
+        assert got.mode == want.mode and got.text == want.text
+        assert [p.page_index for p in got.pages] == [p.page_index for p in want.pages]
+        assert all(p.doc_id == did for p in got.pages)
+    pipe.close()
