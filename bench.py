@@ -4,6 +4,14 @@
 One *step* = one 100-page scanned PDF document taken from PDF bytes to per-page
 text on one GPU: PDF parse -> page image decode -> raster-to-tensor -> DBNet ->
 DB post-process -> line crops -> CRNN -> CTC greedy decode -> strings.
+The K documents of the timed region are queued back to back through the engine
+(DocumentPipeline.process_pdfs): page batches never mix documents, but the
+two-stream pipeline is not drained between documents - the way a worker with a
+queue of uploads runs (BASELINE config 3 is a 10k-page corpus).  All K documents
+are extracted completely inside the timed region.  --sequential finishes each
+document before the next starts; the latency of a single document with nothing
+else in flight is measured before the timed region and reported as
+config.p50_extract_latency_ms.
 With N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL) every
 rank processes its own shard of the corpus (data-parallel page sharding, weak
 scaling: 100 pages per GPU per step); the timed region is bracketed by a
