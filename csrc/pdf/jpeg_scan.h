@@ -63,6 +63,7 @@ inline void build_lut(const Huff& h, uint16_t* lut, int32_t* maxcode, int32_t* v
     for (int i = 0; i < h.bits[len]; ++i, ++k, ++code) {
       if (len <= LUT_BITS) {
         int shift = LUT_BITS - len;
+        if (code >= (1 << len)) return;  // over-subscribed table (rejected by the parser; defence in depth)
         for (int f = 0; f < (1 << shift); ++f) lut[(code << shift) | f] = (uint16_t)((len << 8) | h.vals[k]);
       }
     }
@@ -118,7 +119,17 @@ inline int scan_jpeg(const uint8_t* d, size_t n, JpegInfo* info, JpegTables* tab
         if (tc > 1 || th > 3) return -4;
         Huff& h = huff[tc][th];
         int total = 0;
-        for (int k = 1; k <= 16; ++k) { h.bits[k] = s[q + k]; total += s[q + k]; }
+        // Kraft check: a length-k prefix code has at most 2^k codewords and every codeword of a
+        // shorter length removes two of the next length.  An over-subscribed table would make
+        // build_lut() index past its 2^LUT_BITS entries.
+        long long code = 0;
+        for (int k = 1; k <= 16; ++k) {
+          h.bits[k] = s[q + k];
+          total += s[q + k];
+          code += s[q + k];
+          if (code > (1LL << k)) return -4;
+          code <<= 1;
+        }
         q += 17;
         if (total > 256 || q + total > sl) return -4;
         memcpy(h.vals, s + q, total);
@@ -151,10 +162,15 @@ inline int scan_jpeg(const uint8_t* d, size_t n, JpegInfo* info, JpegTables* tab
       if (!have_sof || sl < 1) return -8;
       int ns = s[0];
       if (sl < 1 + 2 * (size_t)ns + 3) return -8;
+      if (ns < 1 || ns > info->ncomp) return -8;
       for (int k = 0; k < ns; ++k) {
         int cid = s[1 + 2 * k];
+        int td = s[2 + 2 * k] >> 4, ta = s[2 + 2 * k] & 15;
+        if (td > 3 || ta > 3) return -8;  // selectors index huff[2][4]
+        bool matched = false;
         for (int c = 0; c < info->ncomp; ++c)
-          if (comp_id[c] == cid) { info->td[c] = s[2 + 2 * k] >> 4; info->ta[c] = s[2 + 2 * k] & 15; }
+          if (comp_id[c] == cid) { info->td[c] = td; info->ta[c] = ta; matched = true; }
+        if (!matched) return -8;  // a scan component that the frame header does not declare
       }
       info->scan_off = (int64_t)(p + len);
       // one interleaved scan with all components = baseline layout

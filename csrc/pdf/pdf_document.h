@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <functional>
+#include <unordered_set>
 
 #include "pdf_objects.h"
 
@@ -574,8 +575,9 @@ class Document {
     ObjP root = dget(cat, "Pages");
     if (!root) throw PdfError("page tree missing");
     Page inh;
-    std::vector<int> stack;
-    walk_pages(root, inh, 0);
+    std::unordered_set<const Obj*> on_path;
+    size_t visited = 0;
+    walk_pages(root, inh, 0, on_path, visited);
   }
 
   void read_box(const ObjP& a, double* box) {
@@ -586,9 +588,14 @@ class Document {
     box[2] = std::max(v[0], v[2]); box[3] = std::max(v[1], v[3]);
   }
 
-  void walk_pages(const ObjP& node, Page inh, int depth) {
+  // Depth-first over /Kids.  A node already on the current path is a cycle and is skipped; the total node budget
+  // bounds trees that repeat a subtree many times (A.Kids=[B,B], B.Kids=[C,C], ... doubles per level).
+  void walk_pages(const ObjP& node, Page inh, int depth, std::unordered_set<const Obj*>& on_path, size_t& visited) {
     if (!node || node->type != Obj::Dict || depth > 64) return;
     if (pages_.size() > 200000) throw PdfError("too many pages");
+    if (++visited > 1000000) throw PdfError("page tree too large");
+    if (!on_path.insert(node.get()).second) return;
+    struct Pop { std::unordered_set<const Obj*>& s; const Obj* p; ~Pop() { s.erase(p); } } pop{on_path, node.get()};
     ObjP res = dget(node, "Resources");
     if (res && res->type == Obj::Dict) inh.resources = res;
     ObjP mb = dget(node, "MediaBox");
@@ -601,8 +608,7 @@ class Document {
     if (!is_page && kids && kids->type == Obj::Arr) {
       for (auto& k : kids->arr) {
         ObjP kid = resolve(k);
-        if (kid == node) continue;
-        walk_pages(kid, inh, depth + 1);
+        walk_pages(kid, inh, depth + 1, on_path, visited);
       }
       return;
     }

@@ -198,6 +198,58 @@ static void bpe_stress() {
   printf("  bpe: round trips and malformed vocabularies ok\n");
 }
 
+// Hand-built JPEG headers aimed at the table builders: an over-subscribed DHT (more codewords of a length than
+// a prefix code can hold), Huffman selectors outside huff[2][4] in SOS, a scan component the frame never declared,
+// and random mutations of the DHT / SOS payload bytes of an otherwise valid header.
+static void put_seg(std::vector<uint8_t>& j, uint8_t marker, const std::vector<uint8_t>& body) {
+  j.push_back(0xFF); j.push_back(marker);
+  const size_t len = body.size() + 2;
+  j.push_back((uint8_t)(len >> 8)); j.push_back((uint8_t)len);
+  j.insert(j.end(), body.begin(), body.end());
+}
+
+static std::vector<uint8_t> craft_jpeg(const uint8_t* dht_bits, int n_vals, uint8_t sos_sel, uint8_t sos_cid) {
+  std::vector<uint8_t> j = {0xFF, 0xD8};
+  std::vector<uint8_t> dqt(65, 1); dqt[0] = 0;
+  put_seg(j, 0xDB, dqt);
+  put_seg(j, 0xC0, {8, 0, 16, 0, 16, 1, 1, 0x11, 0});
+  for (int tc = 0; tc < 2; ++tc) {
+    std::vector<uint8_t> dht; dht.push_back((uint8_t)(tc << 4));
+    for (int k = 1; k <= 16; ++k) dht.push_back(dht_bits[k]);
+    for (int k = 0; k < n_vals; ++k) dht.push_back((uint8_t)k);
+    put_seg(j, 0xC4, dht);
+  }
+  put_seg(j, 0xDA, {1, sos_cid, sos_sel, 0, 63, 0});
+  for (int k = 0; k < 64; ++k) j.push_back((uint8_t)(k * 37));
+  j.push_back(0xFF); j.push_back(0xD9);
+  return j;
+}
+
+static void jpeg_crafted() {
+  int isz = 0, tsz = 0;
+  dljpeg_sizes(&isz, &tsz);
+  std::vector<uint8_t> jinfo(isz), jtab(tsz);
+  std::vector<uint32_t> segs(64);
+  auto scan = [&](const std::vector<uint8_t>& j) { return dljpeg_scan(j.data(), j.size(), jinfo.data(), jtab.data(), segs.data(), (int)segs.size()); };
+  uint8_t ok_bits[17] = {0, 0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};       // the standard DC-luma table
+  if (scan(craft_jpeg(ok_bits, 12, 0x00, 1)) != 0) { fprintf(stderr, "crafted valid jpeg refused\n"); exit(5); }
+  uint8_t over[17] = {0, 255, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};         // 255 one-bit codewords
+  if (scan(craft_jpeg(over, 255, 0x00, 1)) == 0) { fprintf(stderr, "over-subscribed DHT accepted\n"); exit(5); }
+  uint8_t over2[17] = {0, 2, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};          // full at length 1, one more at 2
+  if (scan(craft_jpeg(over2, 3, 0x00, 1)) == 0) { fprintf(stderr, "over-subscribed DHT (len 2) accepted\n"); exit(5); }
+  if (scan(craft_jpeg(ok_bits, 12, 0xFF, 1)) == 0) { fprintf(stderr, "SOS selector 0xFF accepted\n"); exit(5); }
+  if (scan(craft_jpeg(ok_bits, 12, 0x00, 9)) == 0) { fprintf(stderr, "undeclared scan component accepted\n"); exit(5); }
+  std::mt19937 rng(99);
+  const std::vector<uint8_t> good = craft_jpeg(ok_bits, 12, 0x00, 1);
+  int accepted = 0;
+  for (int it = 0; it < 20000; ++it) {
+    std::vector<uint8_t> m = good;
+    for (int k = 0; k < 1 + (int)(rng() % 6); ++k) m[2 + rng() % (m.size() - 2)] = (uint8_t)rng();
+    accepted += scan(m) == 0;
+  }
+  printf("  jpeg: crafted DHT/SOS headers refused, %d of 20000 mutated headers still parsed\n", accepted);
+}
+
 int main(int argc, char** argv) {
   int iters = 1500;
   for (int i = 1; i < argc; ++i) {
@@ -211,6 +263,7 @@ int main(int argc, char** argv) {
     if (n <= 0) { fprintf(stderr, "well-formed seed did not open\n"); return 2; }
     fuzz_pdf(pdf, iters, 1234u + (uint32_t)i);
   }
+  jpeg_crafted();
   batcher_stress();
   bpe_stress();
   printf("sanitize: OK\n");

@@ -49,6 +49,9 @@ HIP_FLAGS = [
     "-fno-gpu-sanitize",
     "-Wno-unused-result",
     "-DNDEBUG",
+    # no packed-FP32 VALU forms (v_pk_add/mul/fma_f32): hipcc -O3 otherwise forms them from plain float code, and
+    # some of their encodings have produced silently wrong values on this hardware pool
+    "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
 ]
 CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-pthread"]
 
