@@ -28,7 +28,23 @@ RES_NONE, RES_SAME, RES_UP2 = 0, 1, 2
 IntPair = Union[int, Tuple[int, int]]
 
 USE_WEIGHT_FRAGMENTS = True
-LIBRARY_GEMM_MIN_ROWS = 4096      # 0: never call the library GEMM
+LIBRARY_GEMM_MIN_ROWS = 0         # > 0: plain GEMMs with at least this many rows go to hipBLASLt (comparison runs only)
+# The persistent 256 x 256 LDS-DMA kernel (csrc/kernels/gemm_bf16.hip) takes a layer when its tile grid fills the
+# chip and the 256-wide column tile wastes little: every plain linear layer of the recognizers and the wide 3x3
+# convolutions.  cfg 8256 forces it, any other explicit cfg keeps conv_igemm.
+GEMM8_AUTO = True
+GEMM8_MIN_TILES = 192
+CFG_GEMM8 = 8256
+
+
+def gemm8_wanted(M: int, N: int, K: int, cfg: int) -> bool:
+    if cfg == CFG_GEMM8:
+        return True
+    if cfg != 0 or not GEMM8_AUTO:
+        return False
+    tiles_n = (N + 255) // 256
+    waste = tiles_n * 256 / N
+    return waste <= 1.34 and ((M + 255) // 256) * tiles_n >= GEMM8_MIN_TILES
 
 
 def weight_fragments(w: torch.Tensor) -> torch.Tensor:
@@ -204,6 +220,26 @@ def conv2d_nhwc(
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() >= Cout and bias.is_contiguous()
 
+    act_id = ACT[act]
+    rm = res_mode if res is not None else RES_NONE
+    if gemm8_wanted(B * Ho * Wo, Cout, kh * kw * Cin, cfg) and _loader.lib().dlamd_gemm8_serves(
+            B * Ho * Wo, Cout, kh * kw * Cin, Cin, x_cstride, kh, kw, act_id, rm, out_mode, y_cstride, y_coff):
+        prof = PROFILE_SINK
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        rc = _loader.lib().dlamd_gemm8(
+            _loader.ptr(x), _loader.ptr(w), _loader.ptr(bias), _loader.ptr(res if rm != RES_NONE else None), _loader.ptr(y),
+            B, H, W, Cin, x_cstride, Cout, kh, kw, sh, sw, ph, pw, act_id, rm, res_cstride, y_cstride, y_coff,
+            1 if out_dtype == torch.float32 else 0, _loader.stream_ptr())
+        _loader.check(rc, "dlamd_gemm8")
+        if prof is not None:
+            e1.record()
+            prof.append(((B * Ho * Wo, Cout, kh * kw * Cin, f"gemm8 {kh}x{kw} s{sh}{sw} {act} rm{rm}"), e0, e1))
+        return y
+    if cfg == CFG_GEMM8:
+        raise _loader.KernelLibraryError("cfg 8256: the shape is outside the contract of dlamd_gemm8")
+
     frag = None
     if USE_WEIGHT_FRAGMENTS:
         frag = wfrag if wfrag is not None else weight_fragments(w)
@@ -243,8 +279,10 @@ def linear_bf16(
     act: str = "none",
     res: Optional[torch.Tensor] = None,
     out_dtype: torch.dtype = torch.bfloat16,
+    cfg: int = 0,
 ) -> torch.Tensor:
-    """y = act(x @ w^T + bias (+ res)) through the 1x1 path of the conv kernel.
+    """y = act(x @ w^T + bias (+ res)): the persistent GEMM kernel for large layers, the 1x1 path of conv_igemm
+    for small-M / narrow ones.
 
     x: [..., K] bf16, w: [N, K] bf16, bias: [N] f32, res: [..., N] bf16.
     """
@@ -283,7 +321,7 @@ def linear_bf16(
     r2 = None if res is None else res.reshape(1, 1, -1, N)
     y = conv2d_nhwc(
         x2, w.view(N, 1, 1, K), bias, act=act, res=r2, res_mode=RES_SAME if res is not None else RES_NONE,
-        out_dtype=out_dtype, wfrag=weight_fragments(w) if (x.is_cuda and USE_WEIGHT_FRAGMENTS) else None,
+        out_dtype=out_dtype, cfg=cfg,
     )
     return y.reshape(*lead, N)
 
