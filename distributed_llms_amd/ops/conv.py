@@ -232,12 +232,13 @@ def conv2d_nhwc(
             _loader.ptr(x), _loader.ptr(w), _loader.ptr(bias), _loader.ptr(res if rm != RES_NONE else None), _loader.ptr(y),
             B, H, W, Cin, x_cstride, Cout, kh, kw, sh, sw, ph, pw, act_id, rm, res_cstride, y_cstride, y_coff,
             1 if out_dtype == torch.float32 else 0, _loader.stream_ptr())
-        _loader.check(rc, "dlamd_gemm8")
-        if prof is not None:
-            e1.record()
-            prof.append(((B * Ho * Wo, Cout, kh * kw * Cin, f"gemm8 {kh}x{kw} s{sh}{sw} {act} rm{rm}"), e0, e1))
-        return y
-    if cfg == CFG_GEMM8:
+        if rc != -12:          # -12: an operand of 2 GiB or more (32-bit descriptor offsets) -> conv_igemm below
+            _loader.check(rc, "dlamd_gemm8")
+            if prof is not None:
+                e1.record()
+                prof.append(((B * Ho * Wo, Cout, kh * kw * Cin, f"gemm8 {kh}x{kw} s{sh}{sw} {act} rm{rm}"), e0, e1))
+            return y
+    elif cfg == CFG_GEMM8:
         raise _loader.KernelLibraryError("cfg 8256: the shape is outside the contract of dlamd_gemm8")
 
     frag = None
