@@ -34,6 +34,7 @@ struct ImageDesc {
 struct PageCache {
   bool analyzed = false;
   std::string text_visible, text_all;
+  std::string lines_visible, lines_all;   // positioned line records (assemble_lines)
   std::vector<ImageDesc> images;
   size_t chars_visible = 0, chars_invisible = 0, unmapped = 0, decoded = 0;
   double coverage = 0;
@@ -223,6 +224,8 @@ void analyze_page(Handle* h, int page) {
     ci.run_page(pg);
     pc.text_visible = assemble_text(content.spans, false);
     pc.text_all = assemble_text(content.spans, true);
+    pc.lines_visible = assemble_lines(content.spans, false);
+    pc.lines_all = assemble_lines(content.spans, true);
     pc.chars_visible = utf8_len_nows(pc.text_visible);
     pc.chars_invisible = utf8_len_nows(pc.text_all) - pc.chars_visible;
     pc.unmapped = content.unmapped;
@@ -315,6 +318,19 @@ int dlpdf_page_text(void* hp, int page, int include_invisible, const char** out,
   std::lock_guard<std::mutex> g(h->mu);
   analyze_page(h, page);
   const std::string& t = include_invisible ? h->pages[page].text_all : h->pages[page].text_visible;
+  *out = t.data();
+  *len = t.size();
+  return 0;
+}
+
+// Positioned text lines of a page: "x0\ty0\tx1\ty1\tsize\ttext\n" records in page space (y up).  Pointer stays valid
+// until dlpdf_close.
+int dlpdf_page_lines(void* hp, int page, int include_invisible, const char** out, size_t* len) {
+  Handle* h = (Handle*)hp;
+  if (!h || page < 0 || (size_t)page >= h->pages.size()) return -1;
+  std::lock_guard<std::mutex> g(h->mu);
+  analyze_page(h, page);
+  const std::string& t = include_invisible ? h->pages[page].lines_all : h->pages[page].lines_visible;
   *out = t.data();
   *len = t.size();
   return 0;

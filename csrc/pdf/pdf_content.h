@@ -1,6 +1,7 @@
 // Content-stream interpreter: text operators -> positioned spans -> reading-order text;
 // image XObject placements -> page coverage statistics (used by the TXT-vs-OCR classifier).
 #pragma once
+#include <cstdio>
 #include "pdf_fonts.h"
 
 namespace dlpdf {
@@ -283,6 +284,56 @@ inline std::string assemble_text(std::vector<Span> spans, bool include_invisible
       out += para ? "\n\n" : "\n";
     }
     out += t;
+  }
+  return out;
+}
+
+// Spans -> positioned text lines for layout analysis (multi-column reading order).  Spans on one baseline form a
+// line; a horizontal gap wider than 2.5 font sizes (a column gutter, a table cell boundary) starts a new line, so the
+// two columns of a page never fuse into one record.  Output: one record per line,
+//   x0 \t y0 \t x1 \t y1 \t size \t text \n        (page space, y up; tabs / newlines inside text become spaces)
+// in top-to-bottom, left-to-right order.  Ordering across columns is the caller's job.
+inline std::string assemble_lines(std::vector<Span> spans, bool include_invisible) {
+  std::vector<Span*> v;
+  for (auto& s : spans)
+    if ((include_invisible || !s.invisible) && !s.text.empty()) v.push_back(&s);
+  if (v.empty()) return std::string();
+  std::stable_sort(v.begin(), v.end(), [](const Span* a, const Span* b) {
+    if (std::fabs(a->y - b->y) > 0.5 * std::max(1.0, std::min(a->size, b->size))) return a->y > b->y;
+    return a->x < b->x;
+  });
+  struct Line { double x0, x1, y, size; std::string text; };
+  std::vector<Line> lines;
+  const Span* prev = nullptr;
+  for (const Span* s : v) {
+    const double sz = std::max(1.0, s->size);
+    const bool same_base = prev && std::fabs(prev->y - s->y) <= 0.5 * std::max(1.0, std::min(prev->size, s->size));
+    const double gap = prev ? s->x - prev->x_end : 0.0;
+    if (!same_base || gap > 2.5 * sz || gap < -4.0 * sz) {
+      lines.push_back({s->x, std::max(s->x, s->x_end), s->y, sz, s->text});
+    } else {
+      Line& L = lines.back();
+      if (gap > 0.2 * sz && !L.text.empty() && L.text.back() != ' ' && s->text[0] != ' ') L.text.push_back(' ');
+      L.text += s->text;
+      L.size = std::max(L.size, sz);
+      L.x1 = std::max(L.x1, s->x_end);
+    }
+    prev = s;
+  }
+  std::string out;
+  char num[160];
+  for (auto& L : lines) {
+    std::string t = L.text;
+    for (auto& c : t) if (c == '\t' || c == '\n' || c == '\r') c = ' ';
+    while (!t.empty() && t.back() == ' ') t.pop_back();
+    size_t b = 0;
+    while (b < t.size() && t[b] == ' ') ++b;
+    t = t.substr(b);
+    if (t.empty()) continue;
+    snprintf(num, sizeof num, "%.2f\t%.2f\t%.2f\t%.2f\t%.2f\t", L.x0, L.y - 0.25 * L.size, L.x1, L.y + 0.85 * L.size, L.size);
+    out += num;
+    out += t;
+    out.push_back('\n');
   }
   return out;
 }

@@ -1,0 +1,254 @@
+// Page layout analysis in native code: recursive XY-cut reading order over the line boxes (and figure boxes) of a
+// page, with running header / footer detection.  Same algorithm, same thresholds and the same results as
+// distributed_llms_amd/runtime/layout.py, which documents the method and serves as the oracle in the tests; the
+// engine calls this version because it orders every page on its one host thread (tens of microseconds here against
+// milliseconds in numpy).
+//
+// Role in the pipeline: what magic-pdf's layoutreader / xy-cut sort does inside pipe_ocr_mode / pipe_txt_mode in the
+// reference (services/ocr_service/ocr_service.py:215-220, download_models_hf.py:51).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <numeric>
+#include <vector>
+
+namespace {
+
+struct Box { double x0, y0, x1, y1; };
+struct Gap { double width, start, end; };
+
+struct Cutter {
+  const std::vector<Box>& b;
+  double h_med, tx, ty, text_aspect;
+  int min_col_lines;
+  std::vector<int> order;
+  std::vector<int> block_of;
+  int n_blocks = 0;
+
+  Cutter(const std::vector<Box>& boxes, double col_gap, double block_gap, int mcl, double ta)
+      : b(boxes), text_aspect(ta), min_col_lines(mcl), block_of(boxes.size(), 0) {
+    std::vector<double> h;
+    for (auto& x : b) h.push_back(x.y1 - x.y0);
+    h_med = median(h);
+    tx = col_gap * h_med;
+    ty = block_gap * h_med;
+  }
+
+  static double median(std::vector<double> v) {
+    if (v.empty()) return 1.0;
+    std::sort(v.begin(), v.end());
+    const size_t n = v.size();
+    return n % 2 ? v[n / 2] : 0.5 * (v[n / 2 - 1] + v[n / 2]);
+  }
+
+  template <bool Y>
+  std::vector<Gap> gaps(const std::vector<int>& idx) const {
+    std::vector<int> o(idx);
+    std::stable_sort(o.begin(), o.end(), [&](int p, int q) { return (Y ? b[p].y0 : b[p].x0) < (Y ? b[q].y0 : b[q].x0); });
+    std::vector<Gap> out;
+    double reach = Y ? b[o[0]].y1 : b[o[0]].x1;
+    for (size_t k = 1; k < o.size(); ++k) {
+      const double lo = Y ? b[o[k]].y0 : b[o[k]].x0, hi = Y ? b[o[k]].y1 : b[o[k]].x1;
+      if (lo > reach) out.push_back({lo - reach, reach, lo});
+      reach = std::max(reach, hi);
+    }
+    return out;
+  }
+
+  template <bool Y>
+  std::vector<std::vector<int>> split_at(const std::vector<int>& idx, std::vector<double> cuts) const {
+    std::sort(cuts.begin(), cuts.end());
+    std::vector<std::vector<int>> parts(cuts.size() + 1);
+    for (int i : idx) {
+      const double lo = (Y ? b[i].y0 : b[i].x0) + 1e-6;
+      const size_t s = std::lower_bound(cuts.begin(), cuts.end(), lo) - cuts.begin();
+      parts[s].push_back(i);
+    }
+    std::vector<std::vector<int>> out;
+    for (auto& p : parts) if (!p.empty()) out.push_back(std::move(p));
+    return out;
+  }
+
+  void leaf(const std::vector<int>& idx) {
+    std::vector<int> o(idx);
+    auto cy = [&](int i) { return 0.5 * (b[i].y0 + b[i].y1); };
+    std::stable_sort(o.begin(), o.end(), [&](int p, int q) { return cy(p) < cy(q); });
+    size_t start = 0;
+    for (size_t i = 1; i <= o.size(); ++i) {
+      if (i == o.size() || cy(o[i]) - cy(o[start]) > 0.5 * h_med) {
+        std::stable_sort(o.begin() + start, o.begin() + i, [&](int p, int q) { return b[p].x0 < b[q].x0; });
+        start = i;
+      }
+    }
+    for (int i : o) { order.push_back(i); block_of[i] = n_blocks; }
+    ++n_blocks;
+  }
+
+  bool is_text_column(const std::vector<int>& idx) const {
+    if ((int)idx.size() < min_col_lines) return false;
+    std::vector<double> r;
+    for (int i : idx) r.push_back((b[i].x1 - b[i].x0) / std::max(b[i].y1 - b[i].y0, 1.0));
+    return median(r) >= text_aspect;
+  }
+
+  std::vector<double> column_cuts(const std::vector<int>& idx) const {
+    std::vector<double> cuts;
+    for (auto& g : gaps<false>(idx)) if (g.width >= tx) cuts.push_back(0.5 * (g.start + g.end));
+    if (cuts.empty()) return cuts;
+    auto parts = split_at<false>(idx, cuts);
+    if (parts.size() < 2) return {};
+    for (auto& p : parts) if (!is_text_column(p)) return {};
+    return cuts;
+  }
+
+  void cut(const std::vector<int>& idx, int depth) {
+    if (idx.empty()) return;
+    if (idx.size() == 1 || depth > 12) { leaf(idx); return; }
+    auto cuts = column_cuts(idx);
+    if (!cuts.empty()) {
+      for (auto& part : split_at<false>(idx, cuts)) cut(part, depth + 1);
+      return;
+    }
+    std::vector<double> ycuts;
+    for (auto& g : gaps<true>(idx)) if (g.width >= ty) ycuts.push_back(0.5 * (g.start + g.end));
+    if (!ycuts.empty()) {
+      auto parts = split_at<true>(idx, ycuts);
+      if (parts.size() > 1) {
+        size_t i = 0;
+        while (i < parts.size()) {
+          size_t j = i;
+          std::vector<int> merged(parts[i]);
+          while (j + 1 < parts.size()) {
+            std::vector<int> trial(merged);
+            trial.insert(trial.end(), parts[j + 1].begin(), parts[j + 1].end());
+            if (column_cuts(trial).empty()) break;
+            merged.swap(trial);
+            ++j;
+          }
+          cut(merged, depth + 1);
+          i = j + 1;
+        }
+        return;
+      }
+    }
+    double x0 = 1e300, x1 = -1e300;
+    for (int i : idx) { x0 = std::min(x0, b[i].x0); x1 = std::max(x1, b[i].x1); }
+    std::vector<int> wide, rest;
+    for (int i : idx) ((b[i].x1 - b[i].x0) >= 0.6 * (x1 - x0) ? wide : rest).push_back(i);
+    if (!wide.empty() && (int)rest.size() >= 2 * min_col_lines && wide.size() < idx.size() && !column_cuts(rest).empty()) {
+      std::stable_sort(wide.begin(), wide.end(), [&](int p, int q) { return b[p].y0 < b[q].y0; });
+      std::vector<double> ys;
+      for (int k : wide) ys.push_back(0.5 * (b[k].y0 + b[k].y1));
+      std::vector<std::vector<int>> bands(ys.size() + 1);
+      for (int i : rest) {
+        const double c = 0.5 * (b[i].y0 + b[i].y1);
+        bands[std::lower_bound(ys.begin(), ys.end(), c) - ys.begin()].push_back(i);
+      }
+      for (size_t s = 0; s <= ys.size(); ++s) {
+        cut(bands[s], depth + 1);
+        if (s < ys.size()) leaf({wide[s]});
+      }
+      return;
+    }
+    leaf(idx);
+  }
+};
+
+void reading_order(const std::vector<Box>& boxes, std::vector<int>* order, std::vector<int>* block) {
+  order->clear();
+  block->assign(boxes.size(), 0);
+  if (boxes.empty()) return;
+  Cutter c(boxes, 1.2, 0.9, 3, 4.0);
+  std::vector<int> all(boxes.size());
+  std::iota(all.begin(), all.end(), 0);
+  c.cut(all, 0);
+  *order = c.order;
+  *block = c.block_of;
+}
+
+}  // namespace
+
+extern "C" {
+
+// boxes [n][4], figures [nf][4] (x0, y0, x1, y1, y down).  Writes n + nf entries each of order_out (indices into
+// [boxes ; figures]), block_out and kind_out (0 text line, 1 figure), aligned with order_out.  Returns n + nf.
+int dlrt_layout_order(const float* boxes, int n, const float* figs, int nf, float page_h, int* order_out, int* block_out,
+                      int* kind_out) {
+  if (n < 0 || nf < 0) return -1;
+  std::vector<Box> bx(n);
+  for (int i = 0; i < n; ++i) bx[i] = {boxes[4 * i], boxes[4 * i + 1], boxes[4 * i + 2], boxes[4 * i + 3]};
+  // running header / footer: entirely inside the top / bottom 7.5 % of the page, a line height away from the body
+  std::vector<int> head, body, foot;
+  const double band = 0.075;
+  if (n < 3 || page_h <= 0) {
+    for (int i = 0; i < n; ++i) body.push_back(i);
+  } else {
+    std::vector<double> h;
+    for (auto& x : bx) h.push_back(x.y1 - x.y0);
+    const double h_med = Cutter::median(h);
+    std::vector<char> top(n), bot(n);
+    bool any_body = false, any_top = false, any_bot = false;
+    for (int i = 0; i < n; ++i) {
+      top[i] = bx[i].y1 <= band * page_h;
+      bot[i] = bx[i].y0 >= (1.0 - band) * page_h;
+      any_body |= !(top[i] || bot[i]);
+      any_top |= top[i];
+      any_bot |= bot[i];
+    }
+    if (!any_body) {
+      for (int i = 0; i < n; ++i) body.push_back(i);
+    } else {
+      double body_y0 = 1e300, top_y1 = -1e300;
+      for (int i = 0; i < n; ++i) {
+        if (!(top[i] || bot[i])) body_y0 = std::min(body_y0, bx[i].y0);
+        if (top[i]) top_y1 = std::max(top_y1, bx[i].y1);
+      }
+      if (any_top && body_y0 - top_y1 < h_med) std::fill(top.begin(), top.end(), 0);
+      double body_y1 = -1e300, bot_y0 = 1e300;
+      for (int i = 0; i < n; ++i) {
+        if (!(top[i] || bot[i])) body_y1 = std::max(body_y1, bx[i].y1);
+        if (bot[i]) bot_y0 = std::min(bot_y0, bx[i].y0);
+      }
+      if (any_bot && bot_y0 - body_y1 < h_med) {
+        // the footer joins the body; the body's lower edge is unchanged for the header test above (already applied)
+        std::fill(bot.begin(), bot.end(), 0);
+      }
+      for (int i = 0; i < n; ++i) (top[i] ? head : bot[i] ? foot : body).push_back(i);
+    }
+  }
+  int k = 0, nblk = 0;
+  std::vector<int> o, blk;
+  auto emit_group = [&](const std::vector<int>& grp) {
+    std::vector<Box> g;
+    for (int i : grp) g.push_back(bx[i]);
+    reading_order(g, &o, &blk);
+    for (int i : o) { order_out[k] = grp[i]; block_out[k] = nblk; kind_out[k] = 0; ++k; }
+    if (!o.empty()) ++nblk;
+  };
+  emit_group(head);
+  {
+    std::vector<Box> g;
+    for (int i : body) g.push_back(bx[i]);
+    for (int i = 0; i < nf; ++i) g.push_back({figs[4 * i], figs[4 * i + 1], figs[4 * i + 2], figs[4 * i + 3]});
+    reading_order(g, &o, &blk);
+    int mx = -1;
+    for (int i : o) {
+      const bool fig = i >= (int)body.size();
+      order_out[k] = fig ? n + (i - (int)body.size()) : body[i];
+      block_out[k] = nblk + blk[i];
+      kind_out[k] = fig ? 1 : 0;
+      mx = std::max(mx, blk[i]);
+      ++k;
+    }
+    nblk += mx + 1;
+  }
+  {
+    std::vector<Box> g;
+    for (int i : foot) g.push_back(bx[i]);
+    reading_order(g, &o, &blk);
+    for (int i : o) { order_out[k] = foot[i]; block_out[k] = nblk; kind_out[k] = 0; ++k; }
+  }
+  return k;
+}
+
+}  // extern "C"

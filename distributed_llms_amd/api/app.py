@@ -80,14 +80,15 @@ def create_app(settings: Optional[Settings] = None, status: Optional[StatusStore
                 state["results"].ensure_indexes()
             except Exception as e:  # noqa: BLE001
                 logger.error(f"Error initializing MongoDB connection: {str(e)}")
+            os.makedirs(settings.image_dir, exist_ok=True)
+            state["image_writer"] = LocalFileWriter(settings.image_dir)
             if state["extractor"] is None:
                 from ..runtime.extractor import make_extractor
 
                 loop = asyncio.get_running_loop()
-                state["extractor"] = await loop.run_in_executor(None, make_extractor, settings)
+                # figure crops of every document go through the image writer (ocr_service.py:111-124, 198, 216)
+                state["extractor"] = await loop.run_in_executor(None, make_extractor, settings, state["image_writer"])
                 state["own_extractor"] = True
-            os.makedirs(settings.image_dir, exist_ok=True)
-            state["image_writer"] = LocalFileWriter(settings.image_dir)
             jobs = JobManager(state["status"], state["results"], ErrorSink(settings.output_dir), state["extractor"],
                               node_id=settings.node_id, deadline_s=settings.doc_deadline_s)
             state["jobs"] = jobs

@@ -82,6 +82,7 @@ def lib() -> ctypes.CDLL:
             l.dlpdf_was_rebuilt.argtypes = [vp]
             l.dlpdf_page_info.argtypes = [vp, i, ctypes.POINTER(_PageInfo)]
             l.dlpdf_page_text.argtypes = [vp, i, i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz)]
+            l.dlpdf_page_lines.argtypes = [vp, i, i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz)]
             l.dlpdf_page_error.argtypes = [vp, i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz)]
             l.dlpdf_image_info.argtypes = [vp, i, i, ctypes.POINTER(_ImageInfo)]
             l.dlpdf_image_jpeg_bytes.argtypes = [vp, i, i, ctypes.POINTER(vp), ctypes.POINTER(sz)]
@@ -181,11 +182,18 @@ def scan_jpeg(data, max_segments: int = 1 << 20) -> JpegScan:
 class PdfDocument:
     """A parsed PDF.  Holds a reference to the input bytes (the native side reads them in place)."""
 
-    def __init__(self, data: bytes):
-        if not isinstance(data, (bytes, bytearray, memoryview)):
+    def __init__(self, data):
+        """``data``: bytes, bytearray, memoryview or a uint8 ndarray.  Nothing is copied - the native reader works on
+        the caller's buffer in place (a shared-memory view included), which therefore must outlive the document."""
+        if isinstance(data, np.ndarray):
+            if data.dtype != np.uint8 or not data.flags["C_CONTIGUOUS"]:
+                raise TypeError("PdfDocument expects a contiguous uint8 array")
+            self._np = data.reshape(-1)
+        elif isinstance(data, (bytes, bytearray, memoryview)):
+            self._np = np.frombuffer(data, dtype=np.uint8)
+        else:
             raise TypeError("PdfDocument expects bytes")
-        self._data = bytes(data) if not isinstance(data, bytes) else data
-        self._np = np.frombuffer(self._data, dtype=np.uint8)
+        self._data = data
         err = ctypes.create_string_buffer(256)
         self._h = lib().dlpdf_open(self._np.ctypes.data, self._np.size, err, 256)
         if not self._h:
@@ -197,6 +205,9 @@ class PdfDocument:
         if getattr(self, "_h", None):
             lib().dlpdf_close(self._h)
             self._h = None
+        # drop the views so that a shared-memory segment behind them can be unmapped
+        self._np = None
+        self._data = None
 
     def __del__(self):
         try:
@@ -231,6 +242,25 @@ class PdfDocument:
         if lib().dlpdf_page_text(self._h, i, 1 if include_invisible else 0, ctypes.byref(p), ctypes.byref(n)) != 0:
             raise IndexError(i)
         return ctypes.string_at(p, n.value).decode("utf-8", "replace") if n.value else ""
+
+    def page_lines(self, i: int, include_invisible: bool = False) -> List[Tuple[Tuple[float, float, float, float], float, str]]:
+        """Positioned text lines of a page: [((x0, y0, x1, y1), font size, text)] with y measured DOWN from the top
+        of the page (points), in the native reader's top-to-bottom, left-to-right order."""
+        p, n = ctypes.c_char_p(), ctypes.c_size_t()
+        if lib().dlpdf_page_lines(self._h, i, 1 if include_invisible else 0, ctypes.byref(p), ctypes.byref(n)) != 0:
+            raise IndexError(i)
+        if not n.value:
+            return []
+        pi = _PageInfo()
+        lib().dlpdf_page_info(self._h, i, ctypes.byref(pi))
+        out = []
+        for rec in ctypes.string_at(p, n.value).decode("utf-8", "replace").split("\n"):
+            f = rec.split("\t", 5)
+            if len(f) != 6:
+                continue
+            x0, y0, x1, y1, size = (float(v) for v in f[:5])
+            out.append(((x0, pi.height_pt - y1, x1, pi.height_pt - y0), size, f[5]))
+        return out
 
     def page_error(self, i: int) -> str:
         p, n = ctypes.c_char_p(), ctypes.c_size_t()

@@ -69,8 +69,30 @@ def random_text(rng: np.random.Generator, max_chars: int, min_words: int = 1) ->
 
 @dataclass
 class PageTruth:
-    boxes: np.ndarray            # [n, 4] float32 x0, y0, x1, y1 (pixels, reading order)
+    boxes: np.ndarray            # [n, 4] float32 x0, y0, x1, y1 (pixels, reading order; upright page frame)
     texts: List[str] = field(default_factory=list)
+    figures: np.ndarray = field(default_factory=lambda: np.zeros((0, 4), np.float32))   # figure boxes, same frame
+    blocks: List[int] = field(default_factory=list)      # text block id per line (lines of a block form paragraphs)
+    angle: float = 0.0           # degrees the finished page was turned counter-clockwise about its centre (skew)
+    layout: str = "single"
+    font_names: List[str] = field(default_factory=list)
+
+    def rotated_rects(self, size: Tuple[int, int]) -> np.ndarray:
+        """Line boxes in the frame of the skewed image: [n, 5] cx, cy, w, h, angle (degrees, counter-clockwise)."""
+        return rotate_boxes(self.boxes, self.angle, size)
+
+
+def rotate_boxes(boxes: np.ndarray, angle: float, size: Tuple[int, int]) -> np.ndarray:
+    """Upright boxes -> (cx, cy, w, h, angle) after the page was turned ``angle`` degrees counter-clockwise about its
+    centre (image coordinates, y down)."""
+    W, H = size
+    b = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)
+    cx, cy = 0.5 * (b[:, 0] + b[:, 2]) - 0.5 * W, 0.5 * (b[:, 1] + b[:, 3]) - 0.5 * H
+    a = np.deg2rad(angle)
+    # counter-clockwise on screen with y pointing down: x' = x cos + y sin, y' = -x sin + y cos
+    rx, ry = cx * np.cos(a) + cy * np.sin(a), -cx * np.sin(a) + cy * np.cos(a)
+    out = np.stack([rx + 0.5 * W, ry + 0.5 * H, b[:, 2] - b[:, 0], b[:, 3] - b[:, 1], np.full(b.shape[0], angle)], 1)
+    return out.astype(np.float32)
 
 
 def render_page(seed: int, size: Tuple[int, int] = A4_300DPI, font_px: int = 42, noise: float = 2.0,
@@ -119,6 +141,205 @@ def render_page(seed: int, size: Tuple[int, int] = A4_300DPI, font_px: int = 42,
         nz = np.repeat(np.repeat(nz, 4, axis=0), 4, axis=1)[:H, :W]
         arr = np.clip(arr.astype(np.float32) + nz, 0, 255).astype(np.uint8)
     return arr, PageTruth(np.asarray(boxes, dtype=np.float32).reshape(-1, 4), texts)
+
+
+# ------------------------------------------------------------------------------------------- fonts
+_FONT_DIRS = ("/usr/share/fonts/truetype/dejavu",
+              "/usr/local/lib/python3.10/dist-packages/matplotlib/mpl-data/fonts/ttf",
+              "/usr/local/lib/python3.10/dist-packages/kaleido/executable/xdg/fonts/truetype/lato")
+# font files with full ASCII coverage that exist in the build image, by family
+TRAIN_FONTS = ("DejaVuSans.ttf", "DejaVuSans-Bold.ttf", "DejaVuSans-Oblique.ttf", "DejaVuSerif.ttf", "DejaVuSerif-Bold.ttf",
+               "DejaVuSerif-Italic.ttf", "DejaVuSansMono.ttf", "DejaVuSansMono-Bold.ttf", "STIXGeneral.ttf",
+               "STIXGeneralBol.ttf", "STIXGeneralItalic.ttf", "cmr10.ttf", "cmtt10.ttf", "cmb10.ttf")
+HELD_OUT_FONTS = ("Lato-Regular.ttf", "Lato-Bold.ttf", "Lato-Italic.ttf", "cmss10.ttf")   # never rendered in training
+# the Computer Modern files carry TeX encodings: these code points show other glyphs there
+_CM_UNSAFE = set('<>\\_{|}"~^`')
+_FONT_PATHS = {}
+
+
+def font_path(name: str) -> Optional[str]:
+    import os
+
+    if name in _FONT_PATHS:
+        return _FONT_PATHS[name]
+    found = None
+    for d in _FONT_DIRS:
+        p = os.path.join(d, name)
+        if os.path.exists(p):
+            found = p
+            break
+    _FONT_PATHS[name] = found
+    return found
+
+
+def available_fonts(names: Sequence[str]) -> List[str]:
+    return [n for n in names if font_path(n) is not None]
+
+
+def named_font(name: str, size: int) -> ImageFont.FreeTypeFont:
+    key = (name, size)
+    f = _FONT_CACHE.get(key)
+    if f is None:
+        p = font_path(name)
+        f = ImageFont.truetype(p, size) if p else font(size)
+        _FONT_CACHE[key] = f
+    return f
+
+
+def _font_safe(text: str, name: str) -> str:
+    if name.startswith("cm"):
+        return "".join(c for c in text if c not in _CM_UNSAFE).strip()
+    return text
+
+
+def _figure_patch(rng: np.random.Generator, w: int, h: int) -> np.ndarray:
+    """Synthetic "photo / chart" content: a smooth gradient, a few soft blobs and bars, sensor noise."""
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    g = rng.uniform(60, 200) + rng.uniform(-60, 60) * xx / max(w, 1) + rng.uniform(-60, 60) * yy / max(h, 1)
+    for _ in range(int(rng.integers(2, 6))):
+        cx, cy, r = rng.uniform(0, w), rng.uniform(0, h), rng.uniform(0.08, 0.3) * min(w, h)
+        g += rng.uniform(-90, 90) * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * r * r))
+    if rng.random() < 0.5:                       # bar chart
+        nb = int(rng.integers(3, 9))
+        bw = w // (2 * nb + 1)
+        for k in range(nb):
+            bh = int(rng.uniform(0.15, 0.85) * h)
+            g[h - bh : h, (2 * k + 1) * bw : (2 * k + 2) * bw] = rng.uniform(20, 120)
+    g += rng.normal(0, 6, size=g.shape)
+    return np.clip(g, 0, 255).astype(np.uint8)
+
+
+LAYOUTS = ("single", "two_col", "two_col_title", "figure")
+
+
+def render_layout_page(seed: int, size: Tuple[int, int] = A4_300DPI, layout: Optional[str] = None,
+                       fonts: Optional[Sequence[str]] = None, font_px: Optional[int] = None, skew: float = 0.0,
+                       noise: float = 2.0, blur: float = 0.0, margin: Optional[int] = None,
+                       header_footer: Optional[bool] = None) -> Tuple[np.ndarray, PageTruth]:
+    """A synthetic scanned page with a real layout: running header / footer, an optional full-width title, one or
+    two columns of paragraphs, optionally a figure with its caption inside a column; one font per page drawn from
+    ``fonts``; optional skew (degrees), blur and sensor noise.  The truth lists the lines in READING order
+    (header, title, first column top to bottom, second column, footer) in the upright frame plus ``angle``."""
+    W, H = size
+    rng = np.random.default_rng(seed)
+    layout = layout or LAYOUTS[int(rng.integers(len(LAYOUTS)))]
+    fonts = available_fonts(fonts or TRAIN_FONTS) or ["DejaVuSans.ttf"]
+    fname = fonts[int(rng.integers(len(fonts)))]
+    scale = W / 2480.0
+    px = font_px or int(rng.integers(30, 50) * scale)
+    px = max(px, 8)
+    margin = int((margin if margin is not None else 200) * scale) if margin is None or margin > 0 else 0
+    margin = max(margin, 6)
+    paper = int(rng.integers(228, 252))
+    img = Image.new("L", (W, H), paper)
+    d = ImageDraw.Draw(img)
+    f = named_font(fname, px)
+    # headings: the bold sibling where one exists, else the same face larger
+    bold_name = {"DejaVuSans.ttf": "DejaVuSans-Bold.ttf", "DejaVuSerif.ttf": "DejaVuSerif-Bold.ttf",
+                 "DejaVuSansMono.ttf": "DejaVuSansMono-Bold.ttf", "STIXGeneral.ttf": "STIXGeneralBol.ttf",
+                 "Lato-Regular.ttf": "Lato-Bold.ttf", "cmr10.ttf": "cmb10.ttf"}.get(fname, fname)
+    fb = named_font(bold_name if font_path(bold_name) else fname, int(px * 1.3))
+    line_h = int(px * rng.uniform(1.45, 1.7))
+    ink = lambda: int(rng.integers(5, 80))
+    boxes, texts, blocks, figures = [], [], [], []
+    block_id = [0]
+
+    def put(x: int, y: int, t: str, ff, max_x: int) -> Optional[int]:
+        t = _font_safe(t, fname)
+        if not t:
+            return None
+        bb = d.textbbox((x, y), t, font=ff)
+        while bb[2] > max_x and " " in t:        # trim words until the line fits its column
+            t = t.rsplit(" ", 1)[0]
+            bb = d.textbbox((x, y), t, font=ff)
+        if bb[2] > max_x or not t:
+            return None
+        d.text((x, y), t, fill=ink(), font=ff)
+        boxes.append([bb[0] - 3, bb[1] - 3, bb[2] + 3, bb[3] + 3])
+        texts.append(t)
+        blocks.append(block_id[0])
+        return bb[3]
+
+    avg_char = max(1.0, f.getlength("abcdefghij") / 10.0)
+    with_hf = bool(rng.random() < 0.6) if header_footer is None else header_footer
+    top, bottom = margin, H - margin
+    if with_hf:
+        put(margin, int(0.025 * H), random_text(rng, 40).title(), named_font(fname, max(8, int(px * 0.8))), W - margin)
+        block_id[0] += 1
+        top = max(top, int(0.095 * H))
+        bottom = min(bottom, int(0.905 * H))
+    y = top
+    if layout == "two_col_title" or (layout != "single" and rng.random() < 0.3):
+        yb = put(margin, y, random_text(rng, max(8, int((W - 2 * margin) / avg_char / 1.6))).title(), fb, W - margin)
+        block_id[0] += 1
+        y = (yb if yb is not None else y) + int(1.6 * line_h)
+    ncol = 1 if layout in ("single",) else 2
+    if layout == "figure":
+        ncol = int(rng.integers(1, 3))
+    gutter = int(rng.uniform(3.0, 5.0) * px)
+    col_w = (W - 2 * margin - (ncol - 1) * gutter) // ncol
+    fig_col = int(rng.integers(ncol)) if layout == "figure" else -1
+    n_fig = 0
+    for c in range(ncol):
+        x0 = margin + c * (col_w + gutter)
+        x1 = x0 + col_w
+        max_chars = max(6, int(col_w / avg_char))
+        yc = y
+        fig_at = yc + int(rng.uniform(0.1, 0.5) * (bottom - yc)) if c == fig_col else None
+        first = True
+        while yc + line_h < bottom:
+            if fig_at is not None and yc >= fig_at:
+                fh = int(rng.uniform(0.12, 0.25) * H)
+                if yc + fh + 2 * line_h < bottom:
+                    fw = int(rng.uniform(0.7, 1.0) * col_w)
+                    fx = x0 + (col_w - fw) // 2
+                    yc += line_h // 2
+                    img.paste(Image.fromarray(_figure_patch(rng, fw, fh)), (fx, yc))
+                    if rng.random() < 0.5:
+                        d.rectangle([fx, yc, fx + fw - 1, yc + fh - 1], outline=ink(), width=max(1, px // 16))
+                    figures.append([fx, yc, fx + fw, yc + fh])
+                    n_fig += 1
+                    yc += fh + line_h // 2
+                    block_id[0] += 1
+                    yb = put(x0, yc, f"Figure {n_fig}: " + random_text(rng, max(6, max_chars - 12)), f, x1)
+                    block_id[0] += 1
+                    yc = (yb if yb is not None else yc) + line_h
+                fig_at = None
+                continue
+            if first or rng.random() < 0.06:
+                t = random_text(rng, max(6, max_chars // 2)).title()
+                first = False
+                block_id[0] += 1
+                yc += line_h // 3
+                yb = put(x0, yc, t, fb if ncol == 1 else named_font(bold_name if font_path(bold_name) else fname, int(px * 1.1)), x1)
+                yc = (yb if yb is not None else yc) + int(0.9 * line_h)
+                block_id[0] += 1
+                continue
+            frac = 1.0 if rng.random() > 0.16 else float(rng.uniform(0.3, 0.8))
+            t = random_text(rng, max(6, int(max_chars * frac)), min_words=2)
+            put(x0 + (0 if rng.random() > 0.1 else int(rng.integers(1, 4) * px)), yc, t, f, x1)
+            yc += line_h
+            if frac < 1.0 or rng.random() < 0.05:
+                yc += int(rng.uniform(0.9, 1.4) * line_h)       # paragraph gap
+                block_id[0] += 1
+        block_id[0] += 1
+    if with_hf:
+        t = f"{int(rng.integers(1, 400))}" if rng.random() < 0.5 else "Page %d of %d" % (int(rng.integers(1, 50)), 50)
+        put(W // 2 - 2 * px, int(0.945 * H), t, named_font(fname, max(8, int(px * 0.8))), W - margin)
+    if blur > 0:
+        from PIL import ImageFilter
+
+        img = img.filter(ImageFilter.GaussianBlur(blur))
+    if abs(skew) > 1e-3:
+        img = img.rotate(skew, resample=Image.BICUBIC, fillcolor=paper)
+    arr = np.asarray(img, dtype=np.uint8)
+    if noise > 0:
+        nz = rng.normal(0.0, noise, size=(H // 4 + 1, W // 4 + 1)).astype(np.float32)
+        nz = np.repeat(np.repeat(nz, 4, axis=0), 4, axis=1)[:H, :W]
+        arr = np.clip(arr.astype(np.float32) + nz, 0, 255).astype(np.uint8)
+    truth = PageTruth(np.asarray(boxes, dtype=np.float32).reshape(-1, 4), texts,
+                      np.asarray(figures, dtype=np.float32).reshape(-1, 4), blocks, float(skew), layout, [fname])
+    return arr, truth
 
 
 def render_line(text: str, height: int = 48, font_px: int = 34, seed: int = 0, pad: int = 6,
@@ -309,3 +530,41 @@ def make_text_pdf(pages: Sequence[Sequence[str]], font_size: float = 11.0, compr
     w.set(pages_id, b"<< /Type /Pages /Count %d /Kids [%s] >>" % (len(kids), b" ".join(b"%d 0 R" % k for k in kids)))
     w.set(catalog, b"<< /Type /Catalog /Pages %d 0 R >>" % pages_id)
     return w.finish(catalog, xref_stream=xref_stream)
+
+
+def make_text_pdf_columns(columns: Sequence[Sequence[str]], title: Optional[str] = None, font_size: float = 10.0,
+                          header: Optional[str] = None, footer: Optional[str] = None, compress: bool = True) -> bytes:
+    """Born-digital single page with a full-width title and N text columns.  The content stream interleaves the
+    columns LINE BY LINE (row 0 of every column, then row 1, ...), the order in which a layout engine that fills a
+    page top to bottom may emit them - only position-based analysis recovers the reading order."""
+    w = _PdfWriter()
+    catalog = w.reserve()
+    pages_id = w.reserve()
+    font_id = w.add(b"<< /Type /Font /Subtype /Type1 /BaseFont /Helvetica /Encoding /WinAnsiEncoding >>")
+    W, H, margin = 595.28, 841.89, 56.0
+    ncol = max(1, len(columns))
+    gutter = 28.0
+    col_w = (W - 2 * margin - (ncol - 1) * gutter) / ncol
+    lead = font_size * 1.4
+    ops = [b"BT", b"/F1 %.1f Tf" % font_size]
+    if header:
+        ops.append(b"1 0 0 1 %.2f %.2f Tm (%s) Tj" % (margin, H - 30.0, _pdf_escape(header)))
+    y_top = H - 80.0
+    if title:
+        ops.append(b"/F1 %.1f Tf 1 0 0 1 %.2f %.2f Tm (%s) Tj /F1 %.1f Tf" % (font_size * 1.6, margin, y_top, _pdf_escape(title), font_size))
+        y_top -= 3.0 * lead
+    rows = max(len(c) for c in columns) if columns else 0
+    for r in range(rows):
+        for c, col in enumerate(columns):
+            if r < len(col) and col[r]:
+                ops.append(b"1 0 0 1 %.2f %.2f Tm (%s) Tj" % (margin + c * (col_w + gutter), y_top - r * lead, _pdf_escape(col[r])))
+    if footer:
+        ops.append(b"1 0 0 1 %.2f %.2f Tm (%s) Tj" % (W / 2 - 10.0, 28.0, _pdf_escape(footer)))
+    ops.append(b"ET")
+    content = b"\n".join(ops)
+    cid = w.add(w.stream(b"/Filter /FlateDecode", zlib.compress(content)) if compress else w.stream(b"", content))
+    pid = w.add(b"<< /Type /Page /Parent %d 0 R /MediaBox [0 0 %.2f %.2f] /Resources << /Font << /F1 %d 0 R >> >> "
+                b"/Contents %d 0 R >>" % (pages_id, W, H, font_id, cid))
+    w.set(pages_id, b"<< /Type /Pages /Count 1 /Kids [%d 0 R] >>" % pid)
+    w.set(catalog, b"<< /Type /Catalog /Pages %d 0 R >>" % pages_id)
+    return w.finish(catalog)

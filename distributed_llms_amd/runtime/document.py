@@ -28,7 +28,8 @@ import torch
 
 from ..ops import jpeg as jpeg_ops
 from ..pdf import reader
-from .engine import OcrEngine, PageImage, PageResult, StageTimer, TextLine, _to_gray
+from . import layout
+from .engine import Figure, OcrEngine, PageImage, PageResult, StageTimer, TextLine, _to_gray
 
 
 class ExtractionError(RuntimeError):
@@ -44,6 +45,7 @@ class DocumentResult:
     markdown: str = ""
     text: str = ""
     timings: Dict[str, float] = field(default_factory=dict)
+    error: Optional[str] = None                 # set instead of content when the document could not be read
 
 
 _MD_HEADER = re.compile(r"#+\s+")
@@ -66,7 +68,8 @@ def combine_text(content_list: Sequence, markdown: str = "") -> str:
 
 
 def lines_to_paragraphs(lines: Sequence[TextLine]) -> List[str]:
-    """Group recognised lines (already in reading order) into paragraphs by vertical gaps."""
+    """Group recognised lines (already in reading order) into paragraphs: a new paragraph starts at a text-block
+    boundary of the layout analysis, after a vertical gap, or at a clear change of line height."""
     paras: List[List[str]] = []
     prev: Optional[TextLine] = None
     for ln in lines:
@@ -77,7 +80,8 @@ def lines_to_paragraphs(lines: Sequence[TextLine]) -> List[str]:
             h = max(1.0, min(prev.box[3] - prev.box[1], ln.box[3] - ln.box[1]))
             gap = ln.box[1] - prev.box[3]
             same_row = abs((ln.box[1] + ln.box[3]) - (prev.box[1] + prev.box[3])) * 0.5 < 0.5 * h
-            new = not same_row and (gap > 0.8 * h or abs((ln.box[3] - ln.box[1]) - (prev.box[3] - prev.box[1])) > 0.35 * h)
+            new = ln.block != prev.block or (
+                not same_row and (gap > 0.8 * h or abs((ln.box[3] - ln.box[1]) - (prev.box[3] - prev.box[1])) > 0.35 * h))
         if new:
             paras.append([ln.text.strip()])
         else:
@@ -87,17 +91,89 @@ def lines_to_paragraphs(lines: Sequence[TextLine]) -> List[str]:
 
 
 def build_content_list(pages: Sequence[PageResult]) -> List[dict]:
+    """magic-pdf style content list: {'type': 'text', 'text', 'page_idx'} paragraphs and {'type': 'image',
+    'img_path', 'page_idx'} figures in reading order.  Only items with a 'text' key reach the combined text
+    (services/ocr_service/ocr_service.py:229-243)."""
     items = []
     for pg in pages:
-        for para in lines_to_paragraphs(pg.lines):
+        figs = sorted(pg.figures, key=lambda f: f.order)
+        if not figs:
+            for para in lines_to_paragraphs(pg.lines):
+                items.append({"type": "text", "text": para, "page_idx": pg.page_index})
+            continue
+        # figures keep their place in the reading sequence: Figure.order counts lines + figures before it
+        pos, li = 0, 0
+        for fg in figs:
+            take = max(0, fg.order - pos)
+            for para in lines_to_paragraphs(pg.lines[li : li + take]):
+                items.append({"type": "text", "text": para, "page_idx": pg.page_index})
+            li += take
+            pos += take + 1
+            items.append({"type": "image", "img_path": fg.path, "page_idx": pg.page_index,
+                          "bbox": [round(float(v), 1) for v in fg.box]})
+        for para in lines_to_paragraphs(pg.lines[li:]):
             items.append({"type": "text", "text": para, "page_idx": pg.page_index})
     return items
 
 
+def text_layer_page(doc: "reader.PdfDocument", i: int, document_id: str, include_invisible: bool = False) -> PageResult:
+    """A born-digital page as a PageResult: the native reader's positioned text lines put into reading order by the
+    same layout analysis the OCR branch uses (the reference's ``pipe_txt_mode``, ocr_service.py:219-220)."""
+    pi = doc.page_info(i)
+    pr = PageResult(document_id, i, int(round(pi.width_pt)), int(round(pi.height_pt)))
+    recs = doc.page_lines(i, include_invisible=include_invisible)
+    if not recs:
+        return pr
+    boxes = np.asarray([r[0] for r in recs], dtype=np.float32).reshape(-1, 4)
+    order, block, _ = layout.order_page_native(boxes, float(pi.height_pt))
+    for k, j in enumerate(order):
+        box, _size, text = recs[int(j)]
+        pr.lines.append(TextLine(tuple(float(v) for v in box), text, 1.0, int(block[k])))
+    return pr
+
+
+def assemble_document(document_id: str, mode: str, pages: Sequence[PageResult], t0: Optional[float] = None,
+                      image_writer=None) -> "DocumentResult":
+    """Pages -> content list, markdown and combined text (ocr_service.py:223-248).  Figure crops are handed to the
+    image writer here (``LocalFileWriter.write(path, data)``, ocr_service.py:111-124, 216)."""
+    res = DocumentResult(document_id, mode)
+    res.pages = sorted(pages, key=lambda p: p.page_index)
+    if image_writer is not None:
+        write_figures(res.pages, document_id, image_writer)
+    res.content_list = build_content_list(res.pages)
+    res.markdown = "\n\n".join(("![](%s)" % it["img_path"]) if it["type"] == "image" else it["text"] for it in res.content_list)
+    res.text = combine_text(res.content_list, res.markdown)
+    if t0 is not None:
+        res.timings = {"total_s": time.perf_counter() - t0}
+    return res
+
+
+def write_figures(pages: Sequence[PageResult], document_id: str, image_writer) -> int:
+    """Store every figure crop through the image writer as ``<document>/p<page>_f<k>.png``; returns the count."""
+    import io
+
+    from PIL import Image
+
+    n = 0
+    safe = re.sub(r"[^A-Za-z0-9_.-]", "_", document_id or "doc")[:80]
+    for pg in pages:
+        for k, fg in enumerate(pg.figures):
+            if fg.image is None:
+                continue
+            buf = io.BytesIO()
+            Image.fromarray(fg.image).save(buf, format="PNG", compress_level=1)
+            fg.path = f"{safe}/p{pg.page_index}_f{k}.png"
+            image_writer.write(fg.path, buf.getvalue())
+            fg.image = None
+            n += 1
+    return n
+
+
 class DocumentPipeline:
     def __init__(self, engine: OcrEngine, decode_threads: Optional[int] = None, prefetch_batches: int = 2,
-                 ocr_dpi: int = 300):
+                 ocr_dpi: int = 300, image_writer=None):
         self.engine = engine
+        self.image_writer = image_writer        # ``write(path, data)``: receives figure crops (store.results.LocalFileWriter)
         n = decode_threads or min(16, max(2, (os.cpu_count() or 4) // max(1, torch.cuda.device_count() or 1)))
         self.pool = ThreadPoolExecutor(max_workers=n, thread_name_prefix="dlamd-decode")
         self.prefetch = prefetch_batches
@@ -170,78 +246,40 @@ class DocumentPipeline:
     # ------------------------------------------------------------------ entry points
     def process_pdf(self, pdf_bytes: bytes, document_id: str = "", layout_priors=None,
                     force_mode: Optional[str] = None) -> DocumentResult:
-        t0 = time.perf_counter()
-        try:
-            doc = reader.PdfDocument(pdf_bytes)
-        except reader.PdfError as e:
-            raise ExtractionError(f"cannot parse PDF: {e}") from e
-        try:
-            cls = doc.classify()
-            mode = force_mode or ("txt" if cls.is_text else "ocr")
-            t1 = time.perf_counter()
-            self.timer.add("parse", t1 - t0)
-            res = DocumentResult(document_id, mode)
-            n = doc.page_count
-            if n == 0:
-                raise ExtractionError("PDF has no pages")
-            if mode == "txt":
-                for i in range(n):
-                    txt = doc.page_text(i)
-                    for para in txt.split("\n\n"):
-                        para = " ".join(s.strip() for s in para.split("\n") if s.strip())
-                        if para:
-                            res.content_list.append({"type": "text", "text": para, "page_idx": i})
-            else:
-                skipped: List[int] = []
-                pages: List[PageResult] = []
-                for batch_res in self.engine.process_batches(
-                        self._page_batches(doc, list(range(n)), document_id, layout_priors, skipped)):
-                    pages.extend(batch_res)
-                # pages without any image: fall back to whatever text layer they have
-                for i in skipped:
-                    pi = doc.page_info(i)
-                    pr = PageResult(document_id, i, int(pi.width_pt), int(pi.height_pt))
-                    txt = doc.page_text(i, include_invisible=True)
-                    y = 0.0
-                    for para in txt.split("\n\n"):
-                        para = " ".join(s.strip() for s in para.split("\n") if s.strip())
-                        if para:
-                            pr.lines.append(TextLine((0.0, y, 1.0, y + 1.0), para, 1.0))
-                            y += 3.0
-                    pages.append(pr)
-                pages.sort(key=lambda p: p.page_index)
-                res.pages = pages
-                res.content_list = build_content_list(pages)
-            res.markdown = "\n\n".join(it["text"] for it in res.content_list)
-            res.text = combine_text(res.content_list, res.markdown)
-            res.timings = {"total_s": time.perf_counter() - t0, "parse_s": t1 - t0}
-            return res
-        finally:
-            doc.close()
+        """One document, nothing else in flight.  Raises ``ExtractionError`` when it cannot be read."""
+        res = self.process_pdfs([(pdf_bytes, document_id, layout_priors)], force_mode=force_mode)[0]
+        if res.error is not None:
+            raise ExtractionError(res.error)
+        return res
 
     def process_pdfs(self, docs: Sequence[Tuple[bytes, str, Optional[Sequence]]],
                      force_mode: Optional[str] = None) -> List[DocumentResult]:
         """Several documents back to back through ONE engine pipeline: ``docs`` = [(pdf_bytes, document_id,
         layout_priors or None)].  Page batches never mix documents, but the two-stream pipeline is not drained at a
         document boundary (detection of the next document's first batch overlaps recognition of the previous
-        document's last one) - what a worker with a queue of uploads does.  Results come back in input order."""
+        document's last one) - what a worker with a queue of uploads does.  Results come back in input order; a
+        document that cannot be parsed or has no pages yields a result whose ``error`` is set and does not disturb
+        the others."""
         states: List[dict] = []
         try:
             def batches() -> Iterator[List[PageImage]]:
                 for k, (pdf_bytes, did, pri) in enumerate(docs):
                     t0 = time.perf_counter()
+                    st = {"doc": None, "id": did, "mode": "ocr", "n": 0, "skipped": [], "pages": [], "error": None, "t0": t0}
+                    states.append(st)
                     try:
                         doc = reader.PdfDocument(pdf_bytes)
-                    except reader.PdfError as e:
-                        raise ExtractionError(f"cannot parse PDF {did!r}: {e}") from e
-                    cls = doc.classify()
-                    mode = force_mode or ("txt" if cls.is_text else "ocr")
-                    st = {"doc": doc, "id": did, "mode": mode, "n": doc.page_count, "skipped": [], "pages": []}
-                    states.append(st)
-                    self.timer.add("parse", time.perf_counter() - t0)
+                    except (reader.PdfError, TypeError) as e:
+                        st["error"] = f"cannot parse PDF: {e}"
+                        continue
+                    st["doc"] = doc
+                    st["n"] = doc.page_count
                     if st["n"] == 0:
-                        raise ExtractionError(f"PDF {did!r} has no pages")
-                    if mode == "ocr":
+                        st["error"] = "PDF has no pages"
+                        continue
+                    st["mode"] = force_mode or ("txt" if doc.classify().is_text else "ocr")
+                    self.timer.add("parse", time.perf_counter() - t0)
+                    if st["mode"] == "ocr":
                         yield from self._page_batches(doc, list(range(st["n"])), f"{k}\x00{did}", pri, st["skipped"])
 
             for batch_res in self.engine.process_batches(batches()):
@@ -251,45 +289,28 @@ class DocumentPipeline:
                     states[int(k)]["pages"].append(pr)
             out: List[DocumentResult] = []
             for st in states:
-                res = DocumentResult(st["id"], st["mode"])
+                if st["error"] is not None:
+                    res = DocumentResult(st["id"], st["mode"])
+                    res.error = st["error"]
+                    out.append(res)
+                    continue
                 doc = st["doc"]
                 if st["mode"] == "txt":
-                    for i in range(st["n"]):
-                        for para in doc.page_text(i).split("\n\n"):
-                            para = " ".join(x.strip() for x in para.split("\n") if x.strip())
-                            if para:
-                                res.content_list.append({"type": "text", "text": para, "page_idx": i})
+                    pages = [text_layer_page(doc, i, st["id"]) for i in range(st["n"])]
                 else:
-                    pages = st["pages"]
-                    for i in st["skipped"]:
-                        pi = doc.page_info(i)
-                        pr = PageResult(st["id"], i, int(pi.width_pt), int(pi.height_pt))
-                        y = 0.0
-                        for para in doc.page_text(i, include_invisible=True).split("\n\n"):
-                            para = " ".join(x.strip() for x in para.split("\n") if x.strip())
-                            if para:
-                                pr.lines.append(TextLine((0.0, y, 1.0, y + 1.0), para, 1.0))
-                                y += 3.0
-                        pages.append(pr)
-                    pages.sort(key=lambda p: p.page_index)
-                    res.pages = pages
-                    res.content_list = build_content_list(pages)
-                res.markdown = "\n\n".join(it["text"] for it in res.content_list)
-                res.text = combine_text(res.content_list, res.markdown)
+                    # pages without any image: fall back to whatever text layer they have
+                    pages = st["pages"] + [text_layer_page(doc, i, st["id"], include_invisible=True) for i in st["skipped"]]
+                res = assemble_document(st["id"], st["mode"], pages, st["t0"], self.image_writer)
                 out.append(res)
             return out
         finally:
             for st in states:
-                st["doc"].close()
+                if st["doc"] is not None:
+                    st["doc"].close()
 
     def process_rasters(self, images: Sequence[torch.Tensor], document_id: str = "", layout_priors=None
                         ) -> DocumentResult:
         """Already-decoded page rasters (uint8 tensors) -> DocumentResult (OCR branch only)."""
         pages_in = [PageImage(img, document_id, i, None if layout_priors is None else layout_priors[i])
                     for i, img in enumerate(images)]
-        res = DocumentResult(document_id, "ocr")
-        res.pages = self.engine.process_pages(pages_in)
-        res.content_list = build_content_list(res.pages)
-        res.markdown = "\n\n".join(it["text"] for it in res.content_list)
-        res.text = combine_text(res.content_list, res.markdown)
-        return res
+        return assemble_document(document_id, "ocr", self.engine.process_pages(pages_in), None, self.image_writer)

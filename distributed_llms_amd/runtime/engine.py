@@ -37,6 +37,7 @@ from ..ops import dbpost
 from ..ops import jpeg as jpeg_ops
 from ..ops import lstm as lstm_ops
 from ..ops import resample as rs
+from . import layout
 
 
 def _round_up(v: int, m: int) -> int:
@@ -76,6 +77,15 @@ class TextLine:
     box: Tuple[float, float, float, float]
     text: str
     confidence: float
+    block: int = 0               # text block (leaf region of the layout analysis); paragraphs never span blocks
+
+
+@dataclass
+class Figure:
+    box: Tuple[float, float, float, float]
+    order: int = 0               # position in the page's reading sequence (index among lines + figures)
+    image: Optional[np.ndarray] = None     # uint8 crop of the page raster, present until the image writer took it
+    path: str = ""               # where the image writer stored the crop
 
 
 @dataclass
@@ -85,6 +95,7 @@ class PageResult:
     width: int
     height: int
     lines: List[TextLine] = field(default_factory=list)
+    figures: List[Figure] = field(default_factory=list)
     n_detected: int = 0          # boxes the detector itself produced
     used_layout_prior: bool = False
 
@@ -254,7 +265,19 @@ class OcrEngine:
             res = [bx[b, : min(int(nb[b]), self.cfg.db.max_boxes)].copy() for b in range(len(db.pages))]
         else:
             res = db.boxes_host
-        return [dbpost.sort_boxes_reading_order(r) for r in res]
+        out = []
+        for r, p in zip(res, db.pages):
+            # reading order by layout analysis (columns, headings, header / footer); block id rides in column 5
+            r = np.asarray(r, dtype=np.float32).reshape(-1, r.shape[1] if r.ndim == 2 and r.shape[1] else 5)
+            if r.shape[0] == 0:
+                out.append(np.zeros((0, 6), np.float32))
+                continue
+            order, block, _ = layout.order_page_native(r[:, :4], float(p.hw[0]))
+            cols = r[order]
+            if cols.shape[1] < 5:
+                cols = np.concatenate([cols, np.ones((cols.shape[0], 1), np.float32)], 1)
+            out.append(np.concatenate([cols[:, :5], block[:, None].astype(np.float32)], 1))
+        return out
 
     # ------------------------------------------------------------------ recognition stage
     def _plan_crops(self, db: _DetBatch, det_boxes: List[np.ndarray]):
@@ -266,11 +289,15 @@ class OcrEngine:
             n_det = int(bx.shape[0])
             used_prior = False
             b4 = bx[:, :4] if n_det else np.zeros((0, 4), np.float32)
+            blk = bx[:, 5].astype(np.int32) if n_det and bx.shape[1] > 5 else np.zeros((b4.shape[0],), np.int32)
             if p.layout_prior is not None and not self._detections_usable(bx, p):
                 b4 = np.asarray(p.layout_prior, dtype=np.float32).reshape(-1, 4)
+                order, blk, _ = layout.order_page_native(b4, float(p.hw[0]))
+                b4 = b4[order]
                 used_prior = True
             b4 = b4[: cfg.max_lines_per_page]
-            per_page.append((n_det, used_prior, b4))
+            blk = blk[: cfg.max_lines_per_page]
+            per_page.append((n_det, used_prior, b4, blk))
             all_boxes.append(b4)
             all_page.append(np.full((b4.shape[0],), pi, dtype=np.int32))
         boxes = np.concatenate(all_boxes, 0) if all_boxes else np.zeros((0, 4), np.float32)
@@ -487,13 +514,13 @@ class OcrEngine:
             confs[ids] = cf
         results = []
         pos = 0
-        for p, (n_det, used_prior, b4) in zip(rb.det.pages, per_page):
+        for p, (n_det, used_prior, b4, blk) in zip(rb.det.pages, per_page):
             r = PageResult(p.doc_id, p.page_index, p.hw[1], p.hw[0],
                            n_detected=n_det, used_layout_prior=used_prior)
             for k in range(b4.shape[0]):
                 gi = pos + k
                 if ok[gi]:
-                    r.lines.append(TextLine(tuple(float(v) for v in b4[k]), texts[gi], float(confs[gi])))
+                    r.lines.append(TextLine(tuple(float(v) for v in b4[k]), texts[gi], float(confs[gi]), int(blk[k])))
             pos += b4.shape[0]
             self.lines_done += len(r.lines)
             results.append(r)
@@ -524,6 +551,43 @@ class OcrEngine:
             if len(det_q) > 1:
                 rec_q.append(self._advance(det_q.pop(0)))
             if len(rec_q) > 1:
+                yield self._timed_finish(rec_q.pop(0))
+        while det_q:
+            rec_q.append(self._advance(det_q.pop(0)))
+        while rec_q:
+            yield self._timed_finish(rec_q.pop(0))
+
+    STREAM_END = object()
+
+    def run_stream(self, next_batch) -> Iterator[List[PageResult]]:
+        """Continuous form of ``process_batches`` for a service loop.
+
+        ``next_batch(block)`` returns a list of pages, ``None`` when nothing is ready (only when ``block`` is False)
+        or ``OcrEngine.STREAM_END``.  While batches are in flight the engine never blocks on the source: with no new
+        batch it advances the oldest stage instead (wait for the detector, submit recognition, finish), so results of
+        a lone small document are not held back waiting for a successor, and a successor that arrives meanwhile is
+        picked up after one stage."""
+        det_q: List[_DetBatch] = []
+        rec_q: List[_RecBatch] = []
+        slot = 0
+        while True:
+            batch = next_batch(not det_q and not rec_q)
+            if batch is OcrEngine.STREAM_END:
+                break
+            if batch:
+                t0 = time.perf_counter()
+                det_q.append(self._submit_det(batch, slot))
+                slot = (slot + 1) % len(self._streams)
+                self.timer.add("submit_det", time.perf_counter() - t0)
+                if len(det_q) > 1:
+                    rec_q.append(self._advance(det_q.pop(0)))
+                if len(rec_q) > 1:
+                    yield self._timed_finish(rec_q.pop(0))
+            elif det_q:
+                rec_q.append(self._advance(det_q.pop(0)))
+                if len(rec_q) > 1:
+                    yield self._timed_finish(rec_q.pop(0))
+            elif rec_q:
                 yield self._timed_finish(rec_q.pop(0))
         while det_q:
             rec_q.append(self._advance(det_q.pop(0)))

@@ -17,8 +17,7 @@ from typing import Dict, List, Optional
 
 from ..pdf import reader
 from ..store.results import LocalFileWriter
-from .document import DocumentPipeline, DocumentResult, ExtractionError, build_content_list, combine_text
-from .engine import PageResult, TextLine
+from .document import DocumentPipeline, DocumentResult, ExtractionError, assemble_document, text_layer_page
 
 logger = logging.getLogger("distributed_llms_amd")
 
@@ -45,35 +44,64 @@ class Extractor:
         pass
 
 
+def _open_and_classify(pdf_bytes):
+    try:
+        doc = reader.PdfDocument(pdf_bytes)
+    except (reader.PdfError, TypeError) as e:
+        raise ExtractionError(f"cannot parse PDF: {e}") from e
+    try:
+        n = doc.page_count
+        if n == 0:
+            raise ExtractionError("PDF has no pages")
+        return doc, n, ("txt" if doc.classify().is_text else "ocr")
+    except BaseException:
+        doc.close()
+        raise
+
+
 class InlineExtractor(Extractor):
+    """Engine inside the calling process.  Every document goes through ONE continuously running engine loop
+    (runtime/service.py): concurrent uploads share page batches and the two-stream pipeline never drains between
+    documents.  Born-digital documents never touch the engine."""
+
     name = "inline"
 
-    def __init__(self, pipeline: DocumentPipeline):
+    def __init__(self, pipeline: DocumentPipeline, max_wait_ms: float = 3.0, doc_deadline_s: float = 600.0,
+                 hbm_budget_gb: float = 0.0):
+        from .service import EngineService
+
         self.pipeline = pipeline
-        self._lock = threading.Lock()   # one document at a time on the engine's two streams
+        self.doc_deadline_s = doc_deadline_s
+        self.service = EngineService(pipeline, max_wait_ms=max_wait_ms, hbm_budget_bytes=int(hbm_budget_gb * (1 << 30)))
 
     def extract_document(self, pdf_bytes: bytes, document_id: str) -> DocumentResult:
-        with self._lock:
-            return self.pipeline.process_pdf(pdf_bytes, document_id)
+        t0 = time.perf_counter()
+        doc, n, mode = _open_and_classify(pdf_bytes)
+        try:
+            if mode == "txt":
+                pages = [text_layer_page(doc, i, document_id) for i in range(n)]
+            else:
+                got = self.service.submit(doc, list(range(n))).result(timeout=self.doc_deadline_s)
+                pages = []
+                for i in range(n):
+                    pr = got.get(i)
+                    if pr is None:
+                        pr = text_layer_page(doc, i, document_id, include_invisible=True)
+                    pr.doc_id = document_id
+                    pages.append(pr)
+            return assemble_document(document_id, mode, pages, t0, self.pipeline.image_writer)
+        finally:
+            doc.close()
 
     def describe(self):
         e = self.pipeline.engine
-        return {"backend": self.name, "device": str(e.device), "pages_done": e.pages_done, "lines_done": e.lines_done}
+        d = {"backend": self.name, "device": str(e.device), "pages_done": e.pages_done, "lines_done": e.lines_done}
+        d.update(self.service.stats())
+        return d
 
     def close(self) -> None:
+        self.service.close()
         self.pipeline.close()
-
-
-def _text_layer_page(doc: reader.PdfDocument, i: int, document_id: str, include_invisible: bool) -> PageResult:
-    pi = doc.page_info(i)
-    pr = PageResult(document_id, i, int(pi.width_pt), int(pi.height_pt))
-    y = 0.0
-    for para in doc.page_text(i, include_invisible=include_invisible).split("\n\n"):
-        para = " ".join(s.strip() for s in para.split("\n") if s.strip())
-        if para:
-            pr.lines.append(TextLine((0.0, y, 1.0, y + 1.0), para, 1.0))
-            y += 3.0
-    return pr
 
 
 class PoolExtractor(Extractor):
@@ -85,32 +113,18 @@ class PoolExtractor(Extractor):
 
     def extract_document(self, pdf_bytes: bytes, document_id: str) -> DocumentResult:
         t0 = time.perf_counter()
+        doc, n, mode = _open_and_classify(pdf_bytes)
         try:
-            doc = reader.PdfDocument(pdf_bytes)
-        except reader.PdfError as e:
-            raise ExtractionError(f"cannot parse PDF: {e}") from e
-        try:
-            n = doc.page_count
-            if n == 0:
-                raise ExtractionError("PDF has no pages")
-            cls = doc.classify()
-            mode = "txt" if cls.is_text else "ocr"
-            res = DocumentResult(document_id, mode)
             if mode == "txt":
-                res.pages = [_text_layer_page(doc, i, document_id, False) for i in range(n)]
+                pages = [text_layer_page(doc, i, document_id) for i in range(n)]
             else:
                 with_image = [i for i in range(n) if doc.main_image(i) is not None]
                 got = self.pool.submit(pdf_bytes, n, with_image).result(timeout=self.pool.doc_deadline_s + 5)
-                pages: List[PageResult] = []
+                pages = []
                 for i in range(n):
                     pr = got.get(i)
-                    pages.append(pr if pr is not None else _text_layer_page(doc, i, document_id, True))
-                res.pages = pages
-            res.content_list = build_content_list(res.pages)
-            res.markdown = "\n\n".join(it["text"] for it in res.content_list)
-            res.text = combine_text(res.content_list, res.markdown)
-            res.timings = {"total_s": time.perf_counter() - t0}
-            return res
+                    pages.append(pr if pr is not None else text_layer_page(doc, i, document_id, include_invisible=True))
+            return assemble_document(document_id, mode, pages, t0, self.image_writer)
         finally:
             doc.close()
 
@@ -123,9 +137,16 @@ class PoolExtractor(Extractor):
         self.pool.stop()
 
 
-def make_extractor(settings) -> Extractor:
-    """Build the back end a ``Settings`` object asks for (OCR_NUM_GPUS, OCR_* knobs)."""
+def make_extractor(settings, image_writer: Optional[LocalFileWriter] = None) -> Extractor:
+    """Build the back end a ``Settings`` object asks for (OCR_NUM_GPUS, OCR_* knobs).  ``image_writer`` receives the
+    figure crops of every document (the reference passes its ``LocalFileWriter`` into the pipeline the same way,
+    services/ocr_service/ocr_service.py:198, 216)."""
     import torch
+
+    if image_writer is None and getattr(settings, "image_dir", None):
+        image_writer = LocalFileWriter(settings.image_dir)
+    inline_kw = dict(max_wait_ms=getattr(settings, "max_wait_ms", 3.0), doc_deadline_s=getattr(settings, "doc_deadline_s", 600.0),
+                     hbm_budget_gb=getattr(settings, "hbm_budget_gb", 0.0))
 
     from .engine import EngineConfig, OcrEngine
 
@@ -144,17 +165,17 @@ def make_extractor(settings) -> Extractor:
         from .workers import build_engine
 
         engine = build_engine("cpu", {"model": spec_model, "cfg": cfg, "weights_dir": settings.weights_dir, "recognizer": settings.recognizer})
-        return InlineExtractor(DocumentPipeline(engine))
+        return InlineExtractor(DocumentPipeline(engine, image_writer=image_writer), **inline_kw)
     if want == 1 and not getattr(settings, "force_pool", False):
         from .workers import build_engine
 
         engine = build_engine(f"cuda:{ids[0]}", {"model": "full", "cfg": cfg, "weights_dir": settings.weights_dir, "recognizer": settings.recognizer})
         engine.warmup(batch=min(4, settings.max_batch_pages))
-        return InlineExtractor(DocumentPipeline(engine))
+        return InlineExtractor(DocumentPipeline(engine, image_writer=image_writer), **inline_kw)
     from .workers import WorkerPool
 
     pool = WorkerPool([f"cuda:{i}" for i in ids[: min(want, len(ids))]],
                       {"model": "full", "cfg": cfg, "weights_dir": settings.weights_dir, "recognizer": settings.recognizer},
                       fault_inject=settings.fault_inject, max_wait_ms=settings.max_wait_ms,
                       hbm_budget_gb=settings.hbm_budget_gb, doc_deadline_s=settings.doc_deadline_s).start()
-    return PoolExtractor(pool)
+    return PoolExtractor(pool, image_writer)

@@ -1,0 +1,235 @@
+"""Page layout analysis: reading order and text blocks from line boxes.
+
+The reference gets reading order from a learned model (``hantian/layoutreader``,
+services/ocr_service/download_models_hf.py:51) that magic-pdf runs inside ``pipe_ocr_mode`` / ``pipe_txt_mode``
+(ocr_service.py:215-220), with a recursive XY-cut as its own fallback.  No checkpoint is reachable offline, so this
+module is the XY-cut: recursive whitespace cuts over the boxes of a page, the same code for detector boxes of a scan
+and for the text-line boxes the native PDF reader reports for a born-digital page.  Parity with the learned model
+on real documents is unpinned; the behaviours covered by tests are multi-column pages, full-width headings above
+columns, page headers / footers, figures inside a column, and label / value rows (which must NOT be cut).
+
+    order, block_of = reading_order(boxes)          # boxes [n, 4] x0, y0, x1, y1, y down
+
+``order`` lists box indices in reading order; ``block_of[i]`` is the leaf region (text block) of box i - lines of
+different blocks never join one paragraph.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def _gaps(lo: np.ndarray, hi: np.ndarray) -> List[Tuple[float, float, float]]:
+    """Whitespace intervals in the union of [lo, hi] intervals: [(gap width, gap start, gap end)]."""
+    o = np.argsort(lo, kind="stable")
+    out = []
+    reach = hi[o[0]]
+    for k in o[1:]:
+        if lo[k] > reach:
+            out.append((float(lo[k] - reach), float(reach), float(lo[k])))
+        reach = max(reach, hi[k])
+    return out
+
+
+def _split_at(idx: np.ndarray, lo: np.ndarray, cuts: Sequence[float]) -> List[np.ndarray]:
+    """Partition ``idx`` by cut coordinates (each box belongs to the segment its low edge falls in)."""
+    cuts = sorted(cuts)
+    seg = np.searchsorted(np.asarray(cuts), lo[idx] + 1e-6)
+    return [idx[seg == s] for s in range(len(cuts) + 1) if np.any(seg == s)]
+
+
+def _rows_then_x(idx: np.ndarray, b: np.ndarray, h_med: float) -> List[int]:
+    """Leaf order: top to bottom; boxes whose vertical centres are within half a line height form one row, read
+    left to right."""
+    if idx.size <= 1:
+        return [int(i) for i in idx]
+    cy = 0.5 * (b[idx, 1] + b[idx, 3])
+    o = idx[np.argsort(cy, kind="stable")]
+    cy = np.sort(cy, kind="stable")
+    out: List[int] = []
+    start = 0
+    for i in range(1, o.size + 1):
+        if i == o.size or cy[i] - cy[start] > 0.5 * h_med:
+            row = o[start:i]
+            out.extend(int(k) for k in row[np.argsort(b[row, 0], kind="stable")])
+            start = i
+    return out
+
+
+class _Cutter:
+    def __init__(self, boxes: np.ndarray, col_gap: float, block_gap: float, min_col_lines: int, text_aspect: float):
+        self.b = boxes
+        h = boxes[:, 3] - boxes[:, 1]
+        self.h_med = float(np.median(h)) if h.size else 1.0
+        self.tx = col_gap * self.h_med
+        self.ty = block_gap * self.h_med
+        self.min_col_lines = min_col_lines
+        self.text_aspect = text_aspect
+        self.order: List[int] = []
+        self.block_of = np.zeros(boxes.shape[0], dtype=np.int32)
+        self.n_blocks = 0
+
+    def leaf(self, idx: np.ndarray) -> None:
+        for i in _rows_then_x(idx, self.b, self.h_med):
+            self.order.append(i)
+            self.block_of[i] = self.n_blocks
+        self.n_blocks += 1
+
+    def _is_text_column(self, idx: np.ndarray) -> bool:
+        """A side of a vertical cut counts as a column of running text when it holds several lines that are much
+        wider than tall.  Label / value pairs, right-aligned amounts and table cells fail this and stay in rows."""
+        if idx.size < self.min_col_lines:
+            return False
+        w = self.b[idx, 2] - self.b[idx, 0]
+        h = np.maximum(self.b[idx, 3] - self.b[idx, 1], 1.0)
+        return float(np.median(w / h)) >= self.text_aspect
+
+    def column_cuts(self, idx: np.ndarray) -> List[float]:
+        g = [x for x in _gaps(self.b[idx, 0], self.b[idx, 2]) if x[0] >= self.tx]
+        if not g:
+            return []
+        cuts = [0.5 * (s + e) for _, s, e in g]
+        parts = _split_at(idx, self.b[:, 0], cuts)
+        if len(parts) < 2 or not all(self._is_text_column(p) for p in parts):
+            return []
+        return cuts
+
+    def cut(self, idx: np.ndarray, depth: int = 0) -> None:
+        if idx.size == 0:
+            return
+        if idx.size == 1 or depth > 12:
+            self.leaf(idx)
+            return
+        b = self.b
+        # 1. columns first: a gutter that runs through the whole region means the columns are read one after another
+        cuts = self.column_cuts(idx)
+        if cuts:
+            for part in _split_at(idx, b[:, 0], cuts):
+                self.cut(part, depth + 1)
+            return
+        # 2. horizontal whitespace at least a block gap tall: stacked blocks, top to bottom
+        g = [x for x in _gaps(b[idx, 1], b[idx, 3]) if x[0] >= self.ty]
+        if g:
+            parts = _split_at(idx, b[:, 1], [0.5 * (s + e) for _, s, e in g])
+            if len(parts) > 1:
+                # Bands that together still split into columns stay together: the headings of two columns often sit
+                # on one baseline with the same gap below them, and cutting there would read the headings across.
+                i = 0
+                while i < len(parts):
+                    j = i
+                    while j + 1 < len(parts) and self.column_cuts(np.concatenate(parts[i : j + 2])):
+                        j += 1
+                    self.cut(np.concatenate(parts[i : j + 1]), depth + 1)
+                    i = j + 1
+                return
+        # 3. a box spanning the region (full-width heading, wide caption) blocks the gutter: take spanning boxes
+        #    as separators when the rest of the region does split into columns
+        x0, x1 = float(b[idx, 0].min()), float(b[idx, 2].max())
+        wide = idx[(b[idx, 2] - b[idx, 0]) >= 0.6 * (x1 - x0)]
+        rest = idx[(b[idx, 2] - b[idx, 0]) < 0.6 * (x1 - x0)]
+        if wide.size and rest.size >= 2 * self.min_col_lines and wide.size < idx.size and self.column_cuts(rest):
+            wide = wide[np.argsort(b[wide, 1], kind="stable")]
+            ys = [0.5 * (b[k, 1] + b[k, 3]) for k in wide]
+            bands = np.searchsorted(np.asarray(ys), 0.5 * (b[rest, 1] + b[rest, 3]))
+            for s in range(len(ys) + 1):
+                self.cut(rest[bands == s], depth + 1)
+                if s < len(ys):
+                    self.leaf(wide[s : s + 1])
+            return
+        self.leaf(idx)
+
+
+def reading_order(boxes: np.ndarray, col_gap: float = 1.2, block_gap: float = 0.9, min_col_lines: int = 3,
+                  text_aspect: float = 4.0) -> Tuple[np.ndarray, np.ndarray]:
+    """Recursive XY-cut.  ``col_gap`` / ``block_gap`` are the minimum whitespace for a vertical / horizontal cut in
+    units of the median box height.  Returns (order, block id per box)."""
+    boxes = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)
+    n = boxes.shape[0]
+    if n == 0:
+        return np.zeros((0,), np.int64), np.zeros((0,), np.int32)
+    c = _Cutter(boxes, col_gap, block_gap, min_col_lines, text_aspect)
+    c.cut(np.arange(n))
+    return np.asarray(c.order, dtype=np.int64), c.block_of
+
+
+def split_margins(boxes: np.ndarray, page_h: float, band: float = 0.075) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Indices of (header, body, footer) boxes.  A box is a running header / footer when it lies entirely inside
+    the top / bottom ``band`` of the page and the body starts at least a line height away from it."""
+    boxes = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)
+    n = boxes.shape[0]
+    idx = np.arange(n)
+    if n < 3 or page_h <= 0:
+        return idx[:0], idx, idx[:0]
+    h_med = float(np.median(boxes[:, 3] - boxes[:, 1]))
+    top = boxes[:, 3] <= band * page_h
+    bot = boxes[:, 1] >= (1.0 - band) * page_h
+    body = ~(top | bot)
+    if not body.any():
+        return idx[:0], idx, idx[:0]
+    if top.any() and boxes[body, 1].min() - boxes[top, 3].max() < h_med:
+        body |= top
+        top = np.zeros(n, bool)
+    if bot.any() and boxes[bot, 1].min() - boxes[body, 3].max() < h_med:
+        body |= bot
+        bot = np.zeros(n, bool)
+    return idx[top], idx[body], idx[bot]
+
+
+def order_page_native(boxes: np.ndarray, page_h: float, figures: Optional[np.ndarray] = None
+                      ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """``order_page`` through the native implementation (csrc/runtime/layout.cpp): the engine's hot path."""
+    import ctypes
+
+    from .batcher import lib
+
+    l = lib()
+    if not getattr(l, "_layout_declared", False):
+        fp, ip = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)
+        l.dlrt_layout_order.argtypes = [fp, ctypes.c_int, fp, ctypes.c_int, ctypes.c_float, ip, ip, ip]
+        l.dlrt_layout_order.restype = ctypes.c_int
+        l._layout_declared = True
+    b = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 4)
+    f = np.zeros((0, 4), np.float32) if figures is None else np.ascontiguousarray(figures, dtype=np.float32).reshape(-1, 4)
+    n = b.shape[0] + f.shape[0]
+    out = np.empty((3, max(n, 1)), dtype=np.int32)
+    fp, ip = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)
+    k = l.dlrt_layout_order(b.ctypes.data_as(fp), b.shape[0], f.ctypes.data_as(fp), f.shape[0], float(page_h),
+                            out[0].ctypes.data_as(ip), out[1].ctypes.data_as(ip), out[2].ctypes.data_as(ip))
+    if k != n:
+        raise RuntimeError(f"native layout returned {k} of {n} boxes")
+    return out[0, :n].astype(np.int64), out[1, :n].copy(), out[2, :n].copy()
+
+
+def order_page(boxes: np.ndarray, page_h: float, figures: Optional[np.ndarray] = None
+               ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Full-page ordering: header lines, body in XY-cut order (figure boxes take part in the cut as obstacles and
+    keep their place in the sequence), footer lines.
+
+    Returns (order, block id, kind) where ``order`` indexes the concatenation [boxes ; figures] and ``kind`` is 0 for
+    a text line and 1 for a figure, aligned with ``order``."""
+    boxes = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)
+    figs = np.zeros((0, 4)) if figures is None else np.asarray(figures, dtype=np.float64).reshape(-1, 4)
+    nb = boxes.shape[0]
+    head, body, foot = split_margins(boxes, page_h)
+    allb = np.concatenate([boxes[body], figs], axis=0)
+    order_b, block_b = reading_order(allb)
+    order: List[int] = []
+    block: List[int] = []
+    nblk = 0
+    for grp in (head,):
+        o, _ = reading_order(boxes[grp])
+        order += [int(grp[i]) for i in o]
+        block += [nblk] * len(o)
+        nblk += 1 if len(o) else 0
+    for i in order_b:
+        gi = int(body[i]) if i < body.size else nb + int(i - body.size)
+        order.append(gi)
+        block.append(nblk + int(block_b[i]))
+    nblk += int(block_b.max()) + 1 if block_b.size else 0
+    o, _ = reading_order(boxes[foot])
+    order += [int(foot[i]) for i in o]
+    block += [nblk] * len(o)
+    order_a = np.asarray(order, dtype=np.int64)
+    kind = (order_a >= nb).astype(np.int32)
+    return order_a, np.asarray(block, dtype=np.int32), kind

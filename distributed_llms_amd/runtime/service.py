@@ -1,0 +1,185 @@
+"""Continuously running engine loop: every document of a process streams through ONE software pipeline.
+
+The reference extracts each upload in its own pool process, one document at a time per worker
+(services/ocr_service/ocr_service.py:42, 274-278).  Here a single thread owns the GPU engine and never lets its
+two-stream pipeline drain while work exists: pages of all submitted documents are decoded on the host pool, pushed
+into the native dynamic batcher (grouped by detector input shape under the HBM budget) and popped by the engine
+thread as page batches that freely mix documents.  Results are routed back per document.
+
+* an idle engine waits for the batcher's deadline (``max_wait_ms`` after the first page of a bucket arrived) or a
+  full batch; a busy engine only takes batches that are already due and otherwise advances its pipeline;
+* decoded-but-not-yet-consumed pages are bounded (``max_pending_pages``) so a thousand-page upload cannot fill host
+  memory ahead of the GPU;
+* a failure while loading a page fails that document only; a failure inside the engine fails the documents that had
+  pages in flight and the loop carries on.
+"""
+from __future__ import annotations
+
+import logging
+import threading
+import time
+from concurrent.futures import Future
+from typing import Callable, Dict, List, Optional, Sequence
+
+from ..pdf import reader
+from .batcher import DynamicBatcher, page_cost_bytes, shape_key
+from .document import DocumentPipeline
+from .engine import OcrEngine, PageImage, PageResult
+
+logger = logging.getLogger("distributed_llms_amd")
+
+
+class _Job:
+    __slots__ = ("key", "expected", "pages", "future", "mu", "failed", "on_progress", "t0")
+
+    def __init__(self, key: str, expected: int, on_progress: Optional[Callable[[int], None]]):
+        self.key = key
+        self.expected = expected
+        self.pages: Dict[int, Optional[PageResult]] = {}
+        self.future: Future = Future()
+        self.mu = threading.Lock()
+        self.failed = False
+        self.on_progress = on_progress
+        self.t0 = time.perf_counter()
+
+    def done(self, index: int, result: Optional[PageResult]) -> None:
+        with self.mu:
+            if self.failed:
+                return
+            self.pages[index] = result
+            finished = len(self.pages) >= self.expected
+        if self.on_progress is not None:
+            try:
+                self.on_progress(1)
+            except Exception:  # noqa: BLE001 - progress reporting must never break extraction
+                pass
+        if finished and not self.future.done():
+            self.future.set_result(self.pages)
+
+    def fail(self, exc: BaseException) -> None:
+        with self.mu:
+            if self.failed:
+                return
+            self.failed = True
+        if not self.future.done():
+            self.future.set_exception(exc)
+
+
+class EngineService:
+    def __init__(self, pipeline: DocumentPipeline, max_wait_ms: float = 3.0, hbm_budget_bytes: int = 0,
+                 max_pending_pages: Optional[int] = None):
+        self.pipeline = pipeline
+        self.engine: OcrEngine = pipeline.engine
+        self.max_wait_ms = max_wait_ms
+        self.batcher = DynamicBatcher(self.engine.cfg.max_batch_pages, max_wait_ms, hbm_budget_bytes)
+        self._jobs: Dict[str, _Job] = {}
+        self._mu = threading.Lock()
+        self._seq = 0
+        self._slots = threading.Semaphore(max_pending_pages or 8 * self.engine.cfg.max_batch_pages)
+        self._closed = False
+        self.batches = 0
+        self.pages_in_batches = 0
+        self.last_progress = time.time()
+        self.fault_hook: Optional[Callable[[], None]] = None      # tests: called by the engine thread before every batch
+        self._thread = threading.Thread(target=self._run, daemon=True, name="dlamd-engine")
+        self._thread.start()
+
+    # ------------------------------------------------------------------ submission
+    def submit(self, doc: reader.PdfDocument, page_ids: Sequence[int], priors=None,
+               on_progress: Optional[Callable[[int], None]] = None) -> Future:
+        """Queue pages of an open document; resolves to {page index: PageResult, or None for a page without an
+        image}.  The caller keeps ``doc`` open until the future is done."""
+        with self._mu:
+            if self._closed:
+                raise RuntimeError("engine service is closed")
+            self._seq += 1
+            job = _Job(f"j{self._seq}", len(page_ids), on_progress)
+            self._jobs[job.key] = job
+        if not page_ids:
+            job.future.set_result({})
+            self._forget(job)
+            return job.future
+        job.future.add_done_callback(lambda _f, j=job: self._forget(j))
+        for i in page_ids:
+            self.pipeline.pool.submit(self._load_and_push, job, doc, i, None if priors is None else priors[i])
+        return job.future
+
+    def _forget(self, job: _Job) -> None:
+        with self._mu:
+            self._jobs.pop(job.key, None)
+
+    def _load_and_push(self, job: _Job, doc: reader.PdfDocument, i: int, prior) -> None:
+        if job.failed:
+            return
+        self._slots.acquire()
+        pushed = False
+        try:
+            page = self.pipeline._load_page(doc, i, job.key, prior)
+            if page is None:
+                job.done(i, None)
+                return
+            H, W = page.hw
+            _, _, Hd, Wd = self.engine.det_geometry(H, W)
+            self.batcher.push(shape_key(Hd, Wd), page, page_cost_bytes(H, W, Hd, Wd))
+            pushed = True
+        except BaseException as e:  # noqa: BLE001 - one bad page fails its document, not the service
+            job.fail(e if isinstance(e, Exception) else RuntimeError(str(e)))
+        finally:
+            if not pushed:
+                self._slots.release()
+
+    # ------------------------------------------------------------------ engine thread
+    def _next_batch(self, block: bool):
+        if self.fault_hook is not None:
+            self.fault_hook()
+        _, items = self.batcher.pop(timeout_ms=-1.0 if block else 0.0, flush=False)
+        if not items:
+            if self._closed and self.batcher.pending() == 0:
+                return OcrEngine.STREAM_END
+            return None
+        for _ in items:
+            self._slots.release()
+        live: List[PageImage] = []
+        with self._mu:
+            for p in items:
+                job = self._jobs.get(p.doc_id)
+                if job is not None and not job.failed:
+                    live.append(p)
+        self.batches += 1
+        self.pages_in_batches += len(live)
+        return live or None
+
+    def _run(self) -> None:
+        while True:
+            try:
+                for results in self.engine.run_stream(self._next_batch):
+                    self.last_progress = time.time()
+                    for pr in results:
+                        with self._mu:
+                            job = self._jobs.get(pr.doc_id)
+                        if job is not None:
+                            job.done(pr.page_index, pr)
+                return
+            except BaseException as e:  # noqa: BLE001 - fail what was in flight, keep serving
+                logger.error(f"engine loop error: {type(e).__name__}: {e}")
+                with self._mu:
+                    jobs = list(self._jobs.values())
+                for job in jobs:
+                    job.fail(RuntimeError(f"engine failure: {type(e).__name__}: {e}"))
+                if self._closed:
+                    return
+
+    # ------------------------------------------------------------------ lifecycle / stats
+    def stats(self) -> Dict[str, float]:
+        s = dict(self.batcher.stats())
+        s["engine_batches"] = self.batches
+        s["mean_batch_pages"] = round(self.pages_in_batches / self.batches, 2) if self.batches else 0.0
+        with self._mu:
+            s["documents_in_flight"] = len(self._jobs)
+        return s
+
+    def close(self, timeout: float = 10.0) -> None:
+        with self._mu:
+            self._closed = True
+        self.batcher.close()
+        self._thread.join(timeout=timeout)

@@ -82,20 +82,23 @@ def build_engine(device: str, engine_spec: Dict) -> "object":
 
 def worker_main(worker_id: int, device: str, engine_spec: Dict, task_q, result_q, fault_spec: str = "",
                 max_wait_ms: float = 20.0, hbm_budget_gb: float = 200.0) -> None:
-    """Entry point of one GPU worker process."""
+    """Entry point of one GPU worker process: a continuously running engine loop (runtime/service.py) fed with the
+    shards the front end sends.  Shards of different documents share page batches; each shard is answered as soon
+    as its last page is done."""
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     try:
         import numpy as np
         import torch
 
         from ..pdf import reader
-        from .batcher import DynamicBatcher, page_cost_bytes, shape_key
         from .document import DocumentPipeline
+        from .service import EngineService
 
         if device.startswith("cuda"):
             torch.cuda.set_device(torch.device(device))
         engine = build_engine(device, engine_spec)
         pipe = DocumentPipeline(engine)
+        service = EngineService(pipe, max_wait_ms=max_wait_ms, hbm_budget_bytes=int(hbm_budget_gb * (1 << 30)))
         faults = _parse_faults(fault_spec)
         result_q.put(("ready", worker_id, os.getpid()))
     except Exception:
@@ -103,114 +106,80 @@ def worker_main(worker_id: int, device: str, engine_spec: Dict, task_q, result_q
         return
 
     stop = threading.Event()
+    state = {"tasks_done": 0, "tasks_seen": 0}
+    mu = threading.Lock()
 
     def beat():
+        # Liveness follows PROGRESS, not the mere existence of this thread: the beat carries the number of pages the
+        # engine thread has finished.  A worker whose engine is stuck in a GPU call keeps beating (the call releases
+        # the GIL) but its counter stands still, and the front end declares it hung.
         while not stop.wait(0.5):
             try:
-                result_q.put(("hb", worker_id, time.time()))
+                result_q.put(("hb", worker_id, time.time(), engine.pages_done + state["tasks_done"]))
             except Exception:
                 return
 
     threading.Thread(target=beat, daemon=True, name="dlamd-heartbeat").start()
-    tasks_done = 0
-    budget = int(hbm_budget_gb * (1 << 30))
+
+    if faults.get("slow_page_ms"):
+        load_page = pipe._load_page
+
+        def slow_load(*a, **k):
+            time.sleep(faults["slow_page_ms"] / 1000.0)
+            return load_page(*a, **k)
+
+        pipe._load_page = slow_load
+
+    def finish(job_id, shard_id, shm, doc, fut):
+        err = None
+        pages = []
+        try:
+            got = fut.result()
+            for i in sorted(got):
+                pr = got[i]
+                if pr is not None:
+                    pr.doc_id = job_id
+                pages.append((i, pr))
+        except BaseException as e:  # noqa: BLE001 - reported to the front end, the worker lives on
+            err = f"{type(e).__name__}: {e}"
+        finally:
+            try:
+                doc.close()
+            finally:
+                shm.close()
+        if err is not None:
+            result_q.put(("error", worker_id, job_id, shard_id, err))
+        else:
+            result_q.put(("done", worker_id, job_id, shard_id, pages, service.stats()))
+        with mu:
+            state["tasks_done"] += 1
+            done = state["tasks_done"]
+        if faults.get("crash_after_tasks") and done >= int(faults["crash_after_tasks"]) and worker_id == 0:
+            os._exit(17)  # fault injection: die without cleanup, like a GPU fault would
+
     while True:
         task = task_q.get()
         if task is None:
             break
-        round_tasks = [task]
-        # gather whatever else is already waiting: pages of different documents share batches
-        t_end = time.perf_counter() + max_wait_ms / 1000.0
-        while len(round_tasks) < 64:
-            try:
-                t = task_q.get(timeout=max(0.0, t_end - time.perf_counter()))
-            except queue.Empty:
-                break
-            if t is None:
-                task_q.put(None)
-                break
-            round_tasks.append(t)
-        shms, docs = [], {}
-        results: Dict[Tuple[str, int], list] = {}
-        errors: Dict[Tuple[str, int], str] = {}
+        job_id, shard_id, shm_name, nbytes, page_ids = task
+        state["tasks_seen"] += 1
+        if faults.get("hang_after_tasks") and state["tasks_seen"] > int(faults["hang_after_tasks"]) and worker_id == 0:
+            # fault injection: the engine thread stops taking batches (what a wedged GPU call looks like from outside)
+            service.fault_hook = lambda: time.sleep(3600.0)
+        shm = None
         try:
-            batcher = DynamicBatcher(engine.cfg.max_batch_pages, max_wait_ms, budget)
-            total = 0
-            futs = []
-            for (job_id, shard_id, shm_name, nbytes, page_ids) in round_tasks:
-                key = (job_id, shard_id)
-                results[key] = []
-                try:
-                    shm = shared_memory.SharedMemory(name=shm_name)
-                    shms.append(shm)
-                    doc = reader.PdfDocument(bytes(shm.buf[:nbytes]))
-                    docs[key] = doc
-                    for i in page_ids:
-                        futs.append((key, i, pipe.pool.submit(pipe._load_page, doc, i, f"{job_id}\x00{shard_id}", None)))
-                        total += 1
-                except Exception as e:  # unreadable document: fail the shard, keep the worker alive
-                    errors[key] = f"{type(e).__name__}: {e}"
-
-            def producer():
-                for key, i, f in futs:
-                    try:
-                        p = f.result()
-                        if faults.get("slow_page_ms"):
-                            time.sleep(faults["slow_page_ms"] / 1000.0)
-                        if p is None:
-                            # no page image: report an empty page, the front end falls back to the text layer
-                            results[key].append((i, None))
-                            continue
-                        H, W = p.hw
-                        oh, ow, Hd, Wd = engine.det_geometry(H, W)
-                        batcher.push(shape_key(Hd, Wd), p, page_cost_bytes(H, W, Hd, Wd))
-                    except Exception as e:
-                        errors[key] = f"page {i}: {type(e).__name__}: {e}"
-                batcher.close()
-
-            th = threading.Thread(target=producer, daemon=True, name="dlamd-producer")
-            th.start()
-
-            def batches():
-                while True:
-                    _, items = batcher.pop(timeout_ms=-1)
-                    if not items:
-                        return
-                    yield items
-
-            for batch_res in engine.process_batches(batches()):
-                for pr in batch_res:
-                    job_id, shard_id = pr.doc_id.split("\x00")
-                    results[(job_id, int(shard_id))].append((pr.page_index, pr))
-            th.join()
-            stats = batcher.stats()
-        except Exception:
-            tb = traceback.format_exc()
-            for key in results:
-                errors.setdefault(key, tb)
-            stats = {}
-        finally:
-            for d in docs.values():
-                d.close()
-            for s in shms:
-                s.close()
-        for (job_id, shard_id, *_rest) in round_tasks:
-            key = (job_id, shard_id)
-            if key in errors:
-                result_q.put(("error", worker_id, job_id, shard_id, errors[key]))
-            else:
-                pages = []
-                for i, pr in sorted(results[key], key=lambda t: t[0]):
-                    if pr is None:
-                        pages.append((i, None))
-                    else:
-                        pr.doc_id = job_id
-                        pages.append((i, pr))
-                result_q.put(("done", worker_id, job_id, shard_id, pages, stats))
-            tasks_done += 1
-            if faults.get("crash_after_tasks") and tasks_done >= int(faults["crash_after_tasks"]) and worker_id == 0:
-                os._exit(17)  # fault injection: die without cleanup, like a GPU fault would
+            shm = shared_memory.SharedMemory(name=shm_name)
+            # parse in place: the native reader works on the shared-memory mapping itself, nothing is copied
+            doc = reader.PdfDocument(np.frombuffer(shm.buf, dtype=np.uint8, count=nbytes))
+        except Exception as e:  # unreadable document: fail the shard, keep the worker alive
+            if shm is not None:
+                shm.close()
+            result_q.put(("error", worker_id, job_id, shard_id, f"{type(e).__name__}: {e}"))
+            continue
+        fut = service.submit(doc, list(page_ids))
+        fut.add_done_callback(lambda f, a=(job_id, shard_id, shm, doc): finish(*a, f))
     stop.set()
+    service.close()
     pipe.close()
 
 
@@ -240,31 +209,42 @@ class WorkerPool:
     """Front-end handle on the per-GPU worker processes."""
 
     def __init__(self, devices: List[str], engine_spec: Optional[Dict] = None, fault_inject: str = "",
-                 max_wait_ms: float = 20.0, hbm_budget_gb: float = 200.0, min_pages_per_shard: int = 8,
-                 doc_deadline_s: float = 600.0, heartbeat_timeout_s: float = 30.0, max_attempts: int = 3):
+                 max_wait_ms: float = 20.0, hbm_budget_gb: float = 200.0, min_pages_per_shard: int = 32,
+                 doc_deadline_s: float = 600.0, heartbeat_timeout_s: float = 30.0, max_attempts: int = 3,
+                 progress_timeout_s: float = 60.0, max_restarts: int = 5):
         self.devices = list(devices)
         self.engine_spec = engine_spec or {}
         self.fault_inject = fault_inject
         self.max_wait_ms = max_wait_ms
         self.hbm_budget_gb = hbm_budget_gb
+        # a shard smaller than the engine's page batch would run the detector on half-empty batches
         self.min_pages_per_shard = max(1, min_pages_per_shard)
         self.doc_deadline_s = doc_deadline_s
         self.heartbeat_timeout_s = heartbeat_timeout_s
+        self.progress_timeout_s = progress_timeout_s
         self.max_attempts = max_attempts
+        self.max_restarts = max_restarts
         self.ctx = mp.get_context("spawn")     # HIP state must never be forked
         self.result_q = self.ctx.Queue()
-        self.task_qs: List = []
-        self.procs: List = []
-        self.last_beat: List[float] = []
-        self.ready: List[bool] = []
-        self.inflight: List[Dict[Tuple[str, int], _Shard]] = []
+        n = len(self.devices)
+        self.task_qs: List = [None] * n
+        self.procs: List = [None] * n
+        self.last_beat: List[float] = [0.0] * n
+        self.progress: List[int] = [-1] * n            # last progress counter a worker reported
+        self.last_progress: List[float] = [0.0] * n    # when that counter last moved (or a shard came back)
+        self.ready: List[bool] = [False] * n
+        self.failures: List[int] = [0] * n             # consecutive deaths without a finished shard in between
+        self.next_spawn: List[float] = [0.0] * n       # earliest time of the next respawn (exponential backoff)
+        self.disabled: List[bool] = [False] * n        # gave up on this device after max_restarts
+        self.inflight: List[Dict[Tuple[str, int], _Shard]] = [{} for _ in range(n)]
+        self.pending: List[Tuple[str, int]] = []       # shards waiting for a worker to become ready
         self.jobs: Dict[str, _Job] = {}
         self.mu = threading.RLock()
         self._stop = threading.Event()
         self._threads: List[threading.Thread] = []
         self.restarts = 0
         self.pages_done = 0
-        self.batch_stats: Dict[str, int] = {}
+        self.batch_stats: Dict[str, float] = {}
         self._job_seq = 0
 
     # -- lifecycle
@@ -274,15 +254,9 @@ class WorkerPool:
                              args=(wid, self.devices[wid], self.engine_spec, q, self.result_q, fault,
                                    self.max_wait_ms, self.hbm_budget_gb))
         p.start()
-        if wid < len(self.procs):
-            self.task_qs[wid], self.procs[wid] = q, p
-            self.last_beat[wid], self.ready[wid] = time.time(), False
-        else:
-            self.task_qs.append(q)
-            self.procs.append(p)
-            self.last_beat.append(time.time())
-            self.ready.append(False)
-            self.inflight.append({})
+        now = time.time()
+        self.task_qs[wid], self.procs[wid] = q, p
+        self.last_beat[wid], self.last_progress[wid], self.progress[wid], self.ready[wid] = now, now, -1, False
 
     def start(self, wait_ready_s: float = 600.0) -> "WorkerPool":
         for wid in range(len(self.devices)):
@@ -296,22 +270,27 @@ class WorkerPool:
             with self.mu:
                 if all(self.ready):
                     return self
-            if any(not p.is_alive() for p in self.procs):
-                break
+                if any(self.disabled):
+                    break
             time.sleep(0.05)
         with self.mu:
-            if not all(self.ready):
-                raise RuntimeError("GPU workers failed to start (see log for the worker traceback)")
+            ok = all(self.ready)
+        if not ok:
+            self.stop()         # no supervisor may outlive a failed start: it would respawn dying workers forever
+            raise RuntimeError("GPU workers failed to start (see log for the worker traceback)")
         return self
 
     def stop(self) -> None:
         self._stop.set()
         for q in self.task_qs:
             try:
-                q.put(None)
+                if q is not None:
+                    q.put(None)
             except Exception:
                 pass
         for p in self.procs:
+            if p is None:
+                continue
             p.join(timeout=5)
             if p.is_alive():
                 p.terminate()
@@ -336,7 +315,7 @@ class WorkerPool:
         with self.mu:
             self._job_seq += 1
             job_id = f"j{os.getpid()}_{self._job_seq}"
-            nw = self.num_workers
+            nw = max(1, sum(1 for w in range(self.num_workers) if not self.disabled[w]))
             n_shards = max(1, min(nw, (len(ids) + self.min_pages_per_shard - 1) // self.min_pages_per_shard))
             per = (len(ids) + n_shards - 1) // n_shards
             shards = [_Shard(k, ids[k * per : (k + 1) * per]) for k in range(n_shards) if ids[k * per : (k + 1) * per]]
@@ -349,13 +328,21 @@ class WorkerPool:
     def _load(self, wid: int) -> int:
         return sum(len(s.page_ids) for s in self.inflight[wid].values())
 
+    def _usable(self, w: int) -> bool:
+        return self.ready[w] and not self.disabled[w] and self.procs[w] is not None and self.procs[w].is_alive()
+
     def _dispatch(self, job: _Job, s: _Shard, avoid: int = -1) -> None:
-        alive = [w for w in range(self.num_workers) if self.procs[w].is_alive() and w != avoid] or \
-                [w for w in range(self.num_workers) if self.procs[w].is_alive()]
-        if not alive:
-            self._fail(job, "no GPU worker is alive")
+        """Only workers that have reported ready (and not been declared hung since) take work; with none available
+        the shard waits in ``pending`` until the supervisor sees one come up."""
+        cand = [w for w in range(self.num_workers) if self._usable(w) and w != avoid] or \
+               [w for w in range(self.num_workers) if self._usable(w)]
+        if not cand:
+            if all(self.disabled):
+                self._fail(job, "no GPU worker is alive")
+            else:
+                self.pending.append((job.job_id, s.shard_id))
             return
-        w = min(alive, key=self._load)
+        w = min(cand, key=self._load)
         s.worker, s.attempts = w, s.attempts + 1
         self.inflight[w][(job.job_id, s.shard_id)] = s
         self.task_qs[w].put((job.job_id, s.shard_id, job.shm.name, job.nbytes, s.page_ids))
@@ -365,6 +352,7 @@ class WorkerPool:
         for w in range(len(self.inflight)):
             for key in [k for k in self.inflight[w] if k[0] == job.job_id]:
                 self.inflight[w].pop(key, None)
+        self.pending = [k for k in self.pending if k[0] != job.job_id]
         self._release(job)
         if not job.future.done():
             job.future.set_exception(RuntimeError(msg))
@@ -388,17 +376,21 @@ class WorkerPool:
                 return
             kind, wid = msg[0], msg[1]
             with self.mu:
+                now = time.time()
                 if kind == "hb":
-                    self.last_beat[wid] = time.time()
+                    self.last_beat[wid] = now
+                    if len(msg) > 3 and msg[3] != self.progress[wid]:
+                        self.progress[wid], self.last_progress[wid] = msg[3], now
                 elif kind == "ready":
                     self.ready[wid] = True
-                    self.last_beat[wid] = time.time()
+                    self.last_beat[wid] = self.last_progress[wid] = now
                     logger.info(f"GPU worker {wid} ready on {self.devices[wid]} (pid {msg[2]})")
                 elif kind == "fatal":
                     logger.error(f"GPU worker {wid} failed to start:\n{msg[2]}")
                 elif kind in ("done", "error"):
                     job_id, shard_id = msg[2], msg[3]
-                    self.last_beat[wid] = time.time()
+                    self.last_beat[wid] = self.last_progress[wid] = now
+                    self.failures[wid] = 0
                     s = self.inflight[wid].pop((job_id, shard_id), None)
                     job = self.jobs.get(job_id)
                     if job is None or s is None or s.done:
@@ -411,7 +403,8 @@ class WorkerPool:
                         job.pages[i] = pr
                     self.pages_done += len(msg[4])
                     for k, v in (msg[5] or {}).items():
-                        self.batch_stats[k] = self.batch_stats.get(k, 0) + int(v)
+                        if isinstance(v, (int, float)):
+                            self.batch_stats[k] = v
                     if all(x.done for x in job.shards):
                         self.jobs.pop(job_id, None)
                         self._release(job)
@@ -423,21 +416,39 @@ class WorkerPool:
             now = time.time()
             with self.mu:
                 for wid in range(self.num_workers):
-                    p = self.procs[wid]
-                    dead = not p.is_alive()
-                    hung = self.ready[wid] and self.inflight[wid] and now - self.last_beat[wid] > self.heartbeat_timeout_s
-                    if not (dead or hung):
+                    if self.disabled[wid]:
                         continue
-                    logger.error(f"GPU worker {wid} {'died' if dead else 'stopped heartbeating'} "
-                                 f"(exit code {p.exitcode}); re-queueing {len(self.inflight[wid])} shard(s)")
-                    if hung:
+                    p = self.procs[wid]
+                    if p is None:                      # waiting out the backoff of a dead worker
+                        if now >= self.next_spawn[wid]:
+                            self.restarts += 1
+                            self._spawn(wid, "")       # a respawned worker runs without fault injection
+                        continue
+                    dead = not p.is_alive()
+                    # hung: shards in flight but neither a heartbeat, nor any progress of its engine loop, for too long
+                    silent = self.ready[wid] and bool(self.inflight[wid]) and now - self.last_beat[wid] > self.heartbeat_timeout_s
+                    stuck = self.ready[wid] and bool(self.inflight[wid]) and now - self.last_progress[wid] > self.progress_timeout_s
+                    if not (dead or silent or stuck):
+                        continue
+                    why = "died" if dead else ("stopped heartbeating" if silent else "made no progress")
+                    logger.error(f"GPU worker {wid} {why} (exit code {p.exitcode}); re-queueing "
+                                 f"{len(self.inflight[wid])} shard(s)")
+                    if not dead:
                         p.terminate()
-                    orphans = list(self.inflight[wid].values())
-                    keys = list(self.inflight[wid].keys())
+                        p.join(timeout=2)
+                        if p.is_alive():
+                            p.kill()
+                    orphans = list(self.inflight[wid].items())
                     self.inflight[wid].clear()
-                    self.restarts += 1
-                    self._spawn(wid, "")   # a respawned worker runs without fault injection
-                    for (job_id, _), s in zip(keys, orphans):
+                    self.ready[wid] = False
+                    self.procs[wid] = None
+                    self.failures[wid] += 1
+                    if self.failures[wid] > self.max_restarts:
+                        self.disabled[wid] = True
+                        logger.error(f"GPU worker {wid} failed {self.failures[wid]} times in a row: giving up on {self.devices[wid]}")
+                    else:
+                        self.next_spawn[wid] = now + min(30.0, 0.5 * (2 ** (self.failures[wid] - 1)))
+                    for (job_id, _), s in orphans:
                         job = self.jobs.get(job_id)
                         if job is None:
                             continue
@@ -445,12 +456,24 @@ class WorkerPool:
                             self._fail(job, f"shard {s.shard_id} failed on {s.attempts} workers")
                         else:
                             self._dispatch(job, s, avoid=wid)
+                if self.pending and any(self._usable(w) for w in range(self.num_workers)):
+                    waiting, self.pending = self.pending, []
+                    for job_id, shard_id in waiting:
+                        job = self.jobs.get(job_id)
+                        if job is not None:
+                            self._dispatch(job, next(x for x in job.shards if x.shard_id == shard_id))
+                if self.pending and all(self.disabled):
+                    for job_id, _ in list(self.pending):
+                        job = self.jobs.get(job_id)
+                        if job is not None:
+                            self._fail(job, "no GPU worker is alive")
                 for job in list(self.jobs.values()):
                     if now > job.deadline:
                         self._fail(job, f"document deadline of {self.doc_deadline_s:.0f} s exceeded")
 
     def describe(self) -> Dict[str, object]:
         with self.mu:
-            return {"workers": self.num_workers, "alive": sum(p.is_alive() for p in self.procs),
+            return {"workers": self.num_workers, "alive": sum(p is not None and p.is_alive() for p in self.procs),
+                    "ready": sum(self.ready), "disabled": sum(self.disabled),
                     "restarts": self.restarts, "jobs_in_flight": len(self.jobs), "pages_done": self.pages_done,
                     "queue_depth": [self._load(w) for w in range(self.num_workers)], "batcher": dict(self.batch_stats)}

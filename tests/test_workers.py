@@ -96,6 +96,43 @@ def test_dead_worker_is_respawned_and_its_shards_requeued():
         p.stop()
 
 
+def test_hung_worker_is_detected_by_missing_progress_and_replaced():
+    """Worker 0's engine loop wedges after its first shard (its heartbeat thread keeps beating, as it would with the
+    main thread stuck in a GPU call).  The pool notices that the progress counter stands still, kills and respawns
+    the worker, and the shard finishes on the other one."""
+    p = WorkerPool(["cpu", "cpu"], SPEC, fault_inject="hang_after_tasks=1", max_wait_ms=5.0, min_pages_per_shard=2,
+                   doc_deadline_s=120.0, progress_timeout_s=3.0).start(300.0)
+    try:
+        pdf = _scan_pdf(4)
+        assert sorted(p.submit(pdf, 4).result(timeout=120)) == [0, 1, 2, 3]
+        t0 = time.time()
+        assert sorted(p.submit(pdf, 4).result(timeout=120)) == [0, 1, 2, 3]     # worker 0 hangs on this one
+        assert time.time() - t0 < 60, "the hang must be caught by the progress timeout, not the document deadline"
+        t_end = time.time() + 60
+        while p.describe()["restarts"] < 1 and time.time() < t_end:
+            time.sleep(0.1)
+        assert p.describe()["restarts"] >= 1
+        assert sorted(p.submit(pdf, 4).result(timeout=120)) == [0, 1, 2, 3]
+    finally:
+        p.stop()
+
+
+def test_worker_that_cannot_start_is_not_respawned_forever():
+    """A worker that dies at initialisation (here: an engine spec it cannot build) is retried with exponential
+    backoff a bounded number of times; start() then fails AND stops the supervisor."""
+    bad = {"model": "tiny", "cfg": dict(no_such_engine_option=1)}
+    p = WorkerPool(["cpu"], bad, max_restarts=2)
+    t0 = time.time()
+    with pytest.raises(RuntimeError):
+        p.start(120.0)
+    assert time.time() - t0 < 110
+    assert p.describe()["disabled"] == 1 and p.restarts <= 2
+    assert p._stop.is_set()
+    n = p.restarts
+    time.sleep(1.5)
+    assert p.restarts == n, "no respawn after start() failed"
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(300)
 def test_gpu_worker_processes_shard_a_scanned_document():
