@@ -163,7 +163,8 @@ struct DarContext {
   bool imported[DAR_MAX_WORLD] = {};
   uint32_t* status = nullptr;    // separate local allocation
   uint32_t seq = 0;
-  uint32_t spin_limit = 4u << 20;
+  uint32_t spin_limit = 64u << 20;   // polls before a barrier gives up on a peer: tens of seconds (ranks skew by whole
+                                     // data-loader stalls and checkpoint writes; DLAMD_DAR_SPIN_LIMIT / set_spin_limit override)
 };
 
 static size_t dar_flag_bytes(int blocks) {

@@ -38,7 +38,7 @@ from ..store.resp import RespClient
 from ..store.results import ErrorSink, LocalFileWriter, MemoryResultStore, MongoResultStore, ResultStore
 from ..store.status import MemoryStatusStore, RedisStatusStore, StatusStore, public_status
 from ..utils import metrics
-from .multipart import MultipartError, parse_multipart
+from .multipart import MultipartError, StreamingForm, UploadTooLarge, parse_multipart
 
 logger = logging.getLogger("distributed_llms_amd")
 
@@ -130,12 +130,18 @@ def create_app(settings: Optional[Settings] = None, status: Optional[StatusStore
     async def upload_pdf(request: Request):
         try:
             clen = request.headers.get("content-length")
-            if clen and clen.isdigit() and int(clen) > MAX_UPLOAD_BYTES:
+            try:
+                # the body is consumed as it arrives: the cap holds for chunked uploads too, and the file's SHA-256
+                # is computed on an I/O thread while the rest of the upload is still on the wire
+                form = StreamingForm(request.headers.get("content-type"), MAX_UPLOAD_BYTES,
+                                     int(clen) if clen and clen.isdigit() else None,
+                                     hash_pool=request.app.state.ctx["jobs"].io_pool)
+                async for chunk in request.stream():
+                    form.feed(chunk)
+                parts = form.finish()
+            except UploadTooLarge:
                 _count("extract", 413)
                 return JSONResponse({"detail": "upload too large"}, status_code=413)
-            body = await request.body()
-            try:
-                parts = parse_multipart(body, request.headers.get("content-type"))
             except MultipartError as e:
                 _count("extract", 422)
                 return JSONResponse({"detail": f"invalid multipart body: {e}"}, status_code=422)
@@ -155,8 +161,8 @@ def create_app(settings: Optional[Settings] = None, status: Optional[StatusStore
             if not document_id:
                 _count("extract", 400)
                 return JSONResponse({"detail": "document_id is required"}, status_code=400)
-            file_bytes = file_part.data
-            document_hash = hashlib.sha256(file_bytes).hexdigest()
+            file_bytes = file_part.data                 # a view of the receive buffer: the PDF is never copied again
+            document_hash = form.sha256_hex() or hashlib.sha256(file_bytes).hexdigest()
             jobs: JobManager = request.app.state.ctx["jobs"]
             existing = await jobs.claim(document_id, document_hash, file_part.filename or "")
             if existing is not None:

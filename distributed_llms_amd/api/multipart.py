@@ -2,10 +2,14 @@
 
 FastAPI's ``File``/``Form`` need the ``python-multipart`` package (the
 reference depends on it, services/ocr_service/requirements.in); it is not a
-dependency here.  Uploads are whole PDFs that the reference also reads fully
-into memory (ocr_service.py:437), so a single-pass parser over the complete
-body with ``bytes.find`` is both simpler and faster than a streaming state
-machine.
+dependency here.  Two entry points:
+
+* ``parse_multipart(body, content_type)`` - single pass over a complete body;
+* ``StreamingForm`` - fed with the request's chunks as they arrive: the upload cap is enforced while streaming
+  (a chunked upload without Content-Length cannot buffer without limit), the body lands in ONE preallocated buffer,
+  the SHA-256 of the ``file`` part is computed on a helper thread while the rest of the body is still on the wire,
+  and the file's bytes are handed on as a zero-copy view of that buffer (the reference reads the whole upload, then
+  hashes it: ocr_service.py:437-438).
 """
 from __future__ import annotations
 
@@ -16,6 +20,10 @@ from urllib.parse import unquote
 
 
 class MultipartError(ValueError):
+    pass
+
+
+class UploadTooLarge(MultipartError):
     pass
 
 
@@ -32,7 +40,7 @@ class Part:
         return self.filename is not None
 
     def text(self, encoding: str = "utf-8") -> str:
-        return self.data.decode(encoding, "replace")
+        return bytes(self.data).decode(encoding, "replace")
 
 
 _PARAM_RE = re.compile(r';\s*([A-Za-z0-9_\-\*]+)\s*=\s*(?:"((?:[^"\\]|\\.)*)"|([^;\s]*))')
@@ -112,6 +120,187 @@ def parse_multipart(body: bytes, content_type: Optional[str], max_parts: int = 6
         kind, params = parse_header_params(disp)
         if kind != "form-data" or "name" not in params:
             raise MultipartError("Content-Disposition must be form-data with a name")
+        parts.append(Part(name=params["name"], data=data, filename=params.get("filename"),
+                          content_type=headers.get("content-type"), headers=headers))
+        if len(parts) > max_parts:
+            raise MultipartError("too many parts")
+        pos = nxt + 2
+        if pos >= n:
+            raise MultipartError("truncated body")
+    return parts
+
+
+class StreamingForm:
+    """Incremental multipart/form-data reader.  ``feed(chunk)`` for every body chunk, then ``finish()`` -> parts.
+
+    File parts carry ``data`` as a memoryview into the receive buffer; ``sha256_hex(name)`` is the digest of the
+    file part called ``name`` (hashed incrementally on ``hash_pool`` when one is given)."""
+
+    HASH_PIECE = 4 << 20
+
+    def __init__(self, content_type: Optional[str], max_bytes: int, content_length: Optional[int] = None,
+                 hash_field: str = "file", hash_pool=None, max_parts: int = 64):
+        import hashlib
+
+        self.delim = b"--" + boundary_from_content_type(content_type)
+        self.max_bytes = int(max_bytes)
+        if content_length is not None and content_length > self.max_bytes:
+            raise UploadTooLarge("upload too large")
+        self.fixed = content_length is not None and content_length >= 0
+        self.buf = bytearray(content_length) if self.fixed else bytearray()
+        self.n = 0                       # bytes received
+        self.chunks: List[bytes] = []    # without Content-Length: collected, joined once at the end
+        self.hash_field = hash_field
+        self.hash_pool = hash_pool
+        self.max_parts = max_parts
+        self._sha = hashlib.sha256()
+        self._hash_futs = []
+        # incremental scan state (only with a preallocated buffer; otherwise everything happens in finish())
+        self._pos = -1                   # -1: opening delimiter not seen yet
+        self._in_file = False
+        self._data_start = 0
+        self._hashed_to = 0
+        self._file_span = None           # (start, end) of the hashed file part once its closing delimiter is seen
+
+    def feed(self, chunk: bytes) -> None:
+        if not chunk:
+            return
+        if self.n + len(chunk) > self.max_bytes:
+            raise UploadTooLarge("upload too large")
+        if not self.fixed:
+            self.chunks.append(bytes(chunk))
+            self.n += len(chunk)
+            return
+        if self.n + len(chunk) > len(self.buf):
+            raise MultipartError("body longer than its Content-Length")
+        self.buf[self.n : self.n + len(chunk)] = chunk
+        self.n += len(chunk)
+        self._scan()
+
+    # -- incremental scan: find where the hashed file part starts and hash it as it arrives
+    def _scan(self) -> None:
+        if self._file_span is not None:
+            return
+        buf, n, delim = self.buf, self.n, self.delim
+        while not self._in_file:
+            if self._pos < 0:
+                p = buf.find(delim, 0, n)
+                if p < 0:
+                    return
+                self._pos = p
+            p = self._pos + len(delim)
+            if n < p + 2:
+                return
+            if buf[p : p + 2] == b"--":
+                return                                   # closing delimiter: no file part to hash
+            eol = buf.find(b"\r\n", p, n)
+            hdr_end = buf.find(b"\r\n\r\n", p, n) if eol >= 0 else -1
+            if hdr_end < 0:
+                return
+            head = bytes(buf[eol + 2 : hdr_end]).lower()
+            data_start = hdr_end + 4
+            is_target = (b'name="%s"' % self.hash_field.encode()) in head and b"filename" in head
+            if is_target:
+                self._in_file, self._data_start, self._hashed_to = True, data_start, data_start
+                break
+            nxt = buf.find(b"\r\n" + delim, data_start, n)
+            if nxt < 0:
+                return
+            self._pos = nxt + 2
+        if self._in_file:
+            tail = len(delim) + 2
+            scan_from = max(self._data_start, self._hashed_to - tail)
+            end = buf.find(b"\r\n" + delim, scan_from, n)
+            safe = end if end >= 0 else n - tail
+            if end >= 0:
+                self._file_span = (self._data_start, end)
+            while safe - self._hashed_to >= (self.HASH_PIECE if end < 0 else 1):
+                hi = safe if end >= 0 else self._hashed_to + self.HASH_PIECE
+                self._hash_piece(self._hashed_to, hi)
+                self._hashed_to = hi
+
+    def _hash_piece(self, lo: int, hi: int) -> None:
+        view = memoryview(self.buf)[lo:hi]       # the buffer is preallocated and never resized: the view stays valid
+        if self.hash_pool is None:
+            self._sha.update(view)
+        else:
+            # one piece at a time and in order: each task waits for its predecessor
+            prev = self._hash_futs[-1] if self._hash_futs else None
+
+            def run(v=view, prev=prev):
+                if prev is not None:
+                    prev.result()
+                self._sha.update(v)
+
+            self._hash_futs.append(self.hash_pool.submit(run))
+
+    def finish(self) -> List[Part]:
+        import hashlib
+
+        if self.fixed:
+            if self.n != len(self.buf):
+                raise MultipartError("truncated body")
+            body = memoryview(self.buf)
+        else:
+            body = memoryview(b"".join(self.chunks))
+            self.chunks = []
+        parts = _parse_view(body, self.delim, self.max_parts)
+        self._digest = None
+        if self._file_span is not None:
+            for f in self._hash_futs:
+                f.result()
+            tgt = next((p for p in parts if p.name == self.hash_field and p.is_file), None)
+            if tgt is not None and len(tgt.data) == self._file_span[1] - self._file_span[0] and self._hashed_to == self._file_span[1]:
+                self._digest = self._sha.hexdigest()
+        if self._digest is None:
+            tgt = next((p for p in parts if p.name == self.hash_field and p.is_file), None)
+            if tgt is not None:
+                self._digest = hashlib.sha256(tgt.data).hexdigest()
+        return parts
+
+    def sha256_hex(self) -> Optional[str]:
+        return getattr(self, "_digest", None)
+
+
+def _parse_view(body: memoryview, delim: bytes, max_parts: int) -> List[Part]:
+    """``parse_multipart`` over a memoryview; file parts keep views (no copy), form fields become bytes."""
+    raw = body.obj if isinstance(body.obj, (bytes, bytearray)) and len(body.obj) == len(body) else bytes(body)
+    pos = raw.find(delim)
+    if pos < 0:
+        raise MultipartError("opening boundary not found")
+    parts: List[Part] = []
+    n = len(raw)
+    while True:
+        pos += len(delim)
+        if raw[pos:pos + 2] == b"--":
+            break
+        eol = raw.find(b"\r\n", pos)
+        if eol < 0:
+            raise MultipartError("malformed boundary line")
+        pos = eol + 2
+        hdr_end = raw.find(b"\r\n\r\n", pos)
+        if hdr_end < 0:
+            raise MultipartError("part headers not terminated")
+        headers: Dict[str, str] = {}
+        for line in bytes(raw[pos:hdr_end]).split(b"\r\n"):
+            if not line:
+                continue
+            if b":" not in line:
+                raise MultipartError("malformed part header")
+            k, v = line.split(b":", 1)
+            headers[k.decode("latin-1").strip().lower()] = v.decode("utf-8", "replace").strip()
+        data_start = hdr_end + 4
+        nxt = raw.find(b"\r\n" + delim, data_start)
+        if nxt < 0:
+            raise MultipartError("closing boundary not found")
+        disp = headers.get("content-disposition")
+        if disp is None:
+            raise MultipartError("part without Content-Disposition")
+        kind, params = parse_header_params(disp)
+        if kind != "form-data" or "name" not in params:
+            raise MultipartError("Content-Disposition must be form-data with a name")
+        is_file = params.get("filename") is not None
+        data = body[data_start:nxt] if is_file else bytes(raw[data_start:nxt])
         parts.append(Part(name=params["name"], data=data, filename=params.get("filename"),
                           content_type=headers.get("content-type"), headers=headers))
         if len(parts) > max_parts:

@@ -47,13 +47,35 @@ def split_gpus(n_gpus: int, frontends: int) -> List[List[int]]:
 
 
 def count_gpus() -> int:
-    """Device count without initialising the GPU runtime in this (parent) process."""
-    try:
-        import torch
+    """Device count WITHOUT touching the GPU runtime: this process forks and execs every front end and every
+    supervised restart, and a process that has initialised HIP must not exec (``torch.cuda.device_count()`` falls
+    back to ``hipGetDeviceCount`` when amdsmi is missing, which brings HIP up).  Order: ``OCR_NUM_GPUS`` /
+    ``HIP_VISIBLE_DEVICES`` / ``ROCR_VISIBLE_DEVICES`` from the environment, else the KFD topology in sysfs (GPU nodes
+    are the ones with SIMDs)."""
+    env = os.environ.get("OCR_NUM_GPUS", "").strip()
+    if env.lstrip("-").isdigit() and int(env) >= 0:
+        return int(env)
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    return count_kfd_gpus()
 
-        return int(torch.cuda.device_count())
-    except Exception:  # noqa: BLE001
+
+def count_kfd_gpus(root: str = "/sys/class/kfd/kfd/topology/nodes") -> int:
+    n = 0
+    try:
+        for node in os.listdir(root):
+            try:
+                with open(os.path.join(root, node, "properties")) as f:
+                    props = dict(line.split(None, 1) for line in f if " " in line)
+                if int(props.get("simd_count", "0").strip()) > 0:
+                    n += 1
+            except (OSError, ValueError):
+                continue
+    except OSError:
         return 0
+    return n
 
 
 def child_main(fd: int) -> int:

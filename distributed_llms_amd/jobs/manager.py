@@ -121,13 +121,13 @@ class JobManager:
         """``save_results`` (ocr_service.py:339-385): upsert the six-field document, then the preview status."""
         try:
             if result["status"] != "completed":
-                logger.info(f"Not saving to MongoDB - processing not completed for {document_id}")
+                logger.info(f"Result of {document_id} is not stored: extraction did not complete")
                 return False
             text = result["result"]
             self.results.upsert(make_result_document(document_id, text))
             preview = text[:PREVIEW_CHARS] + "..." if len(text) > PREVIEW_CHARS else text
             self.status.update(document_id, {"status": "completed", "result_preview": preview, "completed_at": _now()})
-            logger.info(f"Successfully processed and saved document {document_id} to MongoDB Atlas")
+            logger.info(f"Stored the result document of {document_id}")
             return True
         except Exception as e:  # noqa: BLE001
             logger.error(f"Error saving results for {document_id} to MongoDB: {str(e)}")

@@ -177,8 +177,15 @@ class BucketedDDP:
             self.comm_bytes += b.flat_grad.numel() * b.flat_grad.element_size() // 2
         self.comm_calls += 1
 
-    def finish_backward(self) -> None:
-        """Wait for every bucket's collective (call after loss.backward(), before the optimizer)."""
+    def finish_backward(self, check: bool = True) -> None:
+        """Wait for every bucket's collective (call after loss.backward(), before the optimizer).
+
+        In ``direct`` mode the kernel's barriers are bounded spins: a peer that does not show up in time makes the
+        kernel set a status word and leave, with sums over buffers the peer has not written.  ``check`` reads that
+        word (one 4-byte device-to-host copy, i.e. a stream synchronisation) and raises ``DirectAllReduceError``, so
+        a step never reaches the optimizer with unreduced gradients.  A loop that already synchronises every step
+        (``loss.item()``) loses nothing; one that must not may pass ``check=False`` and call ``check_comm()`` at its
+        own synchronisation points - but then has to discard the steps since the last check on an error."""
         if self.world > 1:
             for b in self.flat.buckets:
                 if b.pending != 0:
@@ -189,7 +196,15 @@ class BucketedDDP:
                     b.handle.wait()
             if self._direct is not None:
                 torch.cuda.current_stream(self.flat.device).wait_stream(self._comm_stream)
+                if check:
+                    self._reset()
+                    self._direct.check()
         self._reset()
+
+    def check_comm(self) -> None:
+        """Raise if any direct all-reduce since the last check ran past a barrier timeout (see finish_backward)."""
+        if self._direct is not None:
+            self._direct.check()
 
     def shard_range(self, b: Bucket):
         n = b.flat_grad.numel() // max(1, self.world)

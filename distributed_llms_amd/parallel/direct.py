@@ -109,7 +109,7 @@ class DirectAllReduce:
         return dst
 
     def set_spin_limit(self, polls: int) -> None:
-        """Polls a barrier makes before it gives up on a peer (default 4 Mi, a few seconds; env DLAMD_DAR_SPIN_LIMIT)."""
+        """Polls a barrier makes before it gives up on a peer (default 64 Mi, tens of seconds; env DLAMD_DAR_SPIN_LIMIT)."""
         self._loader.check(self._l.dlamd_dar_set_spin_limit(self._ctx, int(polls)), "dlamd_dar_set_spin_limit")
 
     def status(self) -> int:

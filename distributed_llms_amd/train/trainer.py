@@ -124,6 +124,7 @@ class CTCTrainer:
                 print(f"[train] step {self.step} loss {loss:.4f} ({rec['time']:.1f}s)", flush=True)
             if self.cfg.ckpt_dir and self.cfg.ckpt_every and self.step % self.cfg.ckpt_every == 0:
                 self.save_checkpoint(self.cfg.ckpt_dir)
+                self._checkpoint_barrier()
         return self.history
 
     # ------------------------------------------------------------------ evaluation through the inference path
@@ -170,6 +171,14 @@ class CTCTrainer:
                 "charset": self.model.charset}
         _atomic(d / "meta.json", lambda p: p.write_text(json.dumps(meta)))
         return d
+
+    def _checkpoint_barrier(self) -> None:
+        """Every rank waits until rank 0 has written the checkpoint: without it the other ranks enter the next step's
+        all-reduce up to a whole file write ahead of rank 0, which a bounded-spin collective reads as a dead peer."""
+        import torch.distributed as dist
+
+        if self.env.world > 1 and dist.is_initialized():
+            dist.barrier()
 
     def load_checkpoint(self, directory: str) -> int:
         from safetensors.torch import load_file

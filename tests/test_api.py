@@ -247,3 +247,50 @@ def test_orphan_sweep_on_startup(ctx):
     with TestClient(app) as c:
         assert c.get("/check-status/stuck").json() == {"status": "error"}
         assert c.get("/check-status/other").json() == {"status": "processing"}
+
+
+# ------------------------------------------------------------------ streaming multipart reader
+def test_streaming_form_matches_one_shot_parser_at_any_chunking():
+    import hashlib
+    import random
+    from concurrent.futures import ThreadPoolExecutor
+
+    from distributed_llms_amd.api.multipart import StreamingForm, encode_multipart, parse_multipart
+
+    rnd = random.Random(5)
+    data = bytes(rnd.getrandbits(8) for _ in range(70_000)) + b"\r\n--not-the-boundary\r\n" + bytes(3000)
+    body, ctype = encode_multipart({"document_id": "doc-1", "note": "x" * 10}, {"file": ("a.pdf", data, "application/pdf")})
+    want = parse_multipart(body, ctype)
+    pool = ThreadPoolExecutor(2)
+    for known_length in (True, False):
+        for _ in range(6):
+            form = StreamingForm(ctype, 1 << 20, len(body) if known_length else None, hash_pool=pool)
+            form.HASH_PIECE = 4096
+            pos = 0
+            while pos < len(body):
+                step = rnd.choice([1, 7, 100, 5000, 40_000])
+                form.feed(body[pos : pos + step])
+                pos += step
+            parts = form.finish()
+            assert [(p.name, p.filename, bytes(p.data)) for p in parts] == [(p.name, p.filename, p.data) for p in want]
+            assert form.sha256_hex() == hashlib.sha256(data).hexdigest()
+
+
+def test_upload_cap_holds_without_content_length(ctx, monkeypatch):
+    """A chunked upload (no Content-Length) is cut off at the cap while it streams, not buffered to the end."""
+    import distributed_llms_amd.api.app as appmod
+    from distributed_llms_amd.api.multipart import encode_multipart
+
+    monkeypatch.setattr(appmod, "MAX_UPLOAD_BYTES", 50_000)
+    body, ctype = encode_multipart({"document_id": "big"}, {"file": ("big.pdf", b"%PDF-" + bytes(200_000), "application/pdf")})
+
+    def gen():
+        for k in range(0, len(body), 8192):
+            yield body[k : k + 8192]
+
+    settings, status, results = ctx
+    app = create_app(settings, status, results, _cpu_extractor())
+    with TestClient(app) as c:
+        r = c.post("/extract", content=gen(), headers={"content-type": ctype})
+        assert r.status_code == 413
+        assert c.get("/check-status/big").status_code == 404

@@ -201,3 +201,51 @@ def test_ctc_trainer_dp2_direct_allreduce_matches_process_group_allreduce():
     assert all(l == l for l in out["direct"][0]["losses"])      # finite
     for l1, l2 in zip(out["direct"][0]["losses"], out["allreduce"][0]["losses"]):
         assert abs(l1 - l2) < 0.05 * max(1.0, abs(l2))
+
+
+def _late_peer_rank(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import time
+
+    from distributed_llms_amd.parallel.ddp import BucketedDDP
+    from distributed_llms_amd.parallel.direct import DirectAllReduceError
+
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 64), torch.nn.ReLU(), torch.nn.Linear(64, 8)).cuda()
+    ddp = BucketedDDP(net, mode="direct")
+    assert ddp.mode == "direct"
+    x = torch.randn(16, 64, device="cuda")
+    # a normal step first: both ranks arrive together, the check passes
+    net(x).sum().backward()
+    ddp.finish_backward()
+    ddp.zero_grad()
+    dist.barrier()
+    # now the barriers give up after a few thousand polls (microseconds) and rank 1 is a second late: rank 0's
+    # kernel leaves with its status word set (it still exits normally - nothing hangs) and the step must raise
+    ddp._direct.set_spin_limit(2000)
+    if rank == 1:
+        time.sleep(1.0)
+    net(x).sum().backward()
+    raised = False
+    try:
+        ddp.finish_backward()
+    except DirectAllReduceError:
+        raised = True
+    torch.cuda.synchronize()
+    with open(os.path.join(out_dir, f"r{rank}.txt"), "w") as f:
+        f.write("raised" if raised else "ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_bucketed_ddp_raises_when_a_peer_misses_the_barrier():
+    """A rank that arrives after the bounded spin has run out must fail the step on the rank that waited: silently
+    proceeding would feed unreduced gradients to the optimizer and leave the ranks out of sync for good."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_late_peer_rank, args=(2, _free_port(), d), nprocs=2, join=True)
+        got = [open(os.path.join(d, f"r{r}.txt")).read() for r in range(2)]
+    assert got[0] == "raised", got

@@ -90,3 +90,23 @@ def test_two_front_ends_share_one_port_and_the_stores(tmp_path, monkeypatch):
         assert sup.children[0].pid != victim.pid and sup.restarts == 1
     finally:
         sup.shutdown()
+
+
+def test_gpu_count_never_touches_the_gpu_runtime(tmp_path, monkeypatch):
+    from distributed_llms_amd.api import serve
+
+    for var in ("OCR_NUM_GPUS", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    # a fake KFD topology: one CPU node (no SIMDs) and three GPU nodes
+    for k, simd in enumerate((0, 1024, 1024, 1024)):
+        d = tmp_path / str(k)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {16 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    assert serve.count_kfd_gpus(str(tmp_path)) == 3
+    assert serve.count_kfd_gpus(str(tmp_path / "missing")) == 0
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1")
+    assert serve.count_gpus() == 2
+    monkeypatch.setenv("OCR_NUM_GPUS", "5")
+    assert serve.count_gpus() == 5
+    import sys
+    assert "torch" not in serve.count_gpus.__code__.co_names
