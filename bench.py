@@ -62,6 +62,9 @@ def parse_args():
     ap.add_argument("--input", choices=["pdf", "raster"], default="pdf",
                     help="pdf: timed region starts from PDF bytes (parse + image decode); raster: decoded u8 pages")
     ap.add_argument("--codec", choices=["jpeg", "flate"], default="jpeg")
+    ap.add_argument("--restart-blocks", type=int, default=0,
+                    help="MCUs per JPEG restart interval; 0 (default) = no restart markers, what scanners write")
+    ap.add_argument("--color", choices=["gray", "rgb"], default="gray", help="colour space of the page images")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--cpu", action="store_true", help="debug: tiny model on CPU")
     ap.add_argument("--stage-times", action="store_true")
@@ -137,10 +140,17 @@ def main():
     truth_boxes = [rendered[i % n_dist][1].boxes for i in range(args.pages_per_doc)]
     lines_per_page = float(np.mean([len(p) for p in truth_boxes]))
     priors = None if trained else truth_boxes      # trained detector: no hints of any kind
+    if args.color == "rgb":
+        # a colour scan of a black-on-white page: paper tint in the chroma planes, same luma content
+        tint = np.array([1.0, 0.97, 0.9], dtype=np.float32)
+        pages = [np.clip(p[..., None].astype(np.float32) * tint, 0, 255).astype(np.uint8) for p in pages]
+    images = ("%s %s" % (args.color, "JPEG q85 without restart markers" if args.restart_blocks == 0 else
+                         "JPEG q85 with a restart marker every %d MCUs" % args.restart_blocks)
+              if args.codec == "jpeg" else "%s Flate (zlib level 1)" % args.color)
     if args.input == "pdf":
         enc = None
         if args.codec == "jpeg":
-            enc_d = [synth.encode_page_jpeg(rendered[i][0]) for i in range(n_dist)]
+            enc_d = [synth.encode_page_jpeg(pages[i], restart_blocks=args.restart_blocks) for i in range(n_dist)]
             enc = [enc_d[i % n_dist] for i in range(args.pages_per_doc)]
         pdf_bytes = synth.make_scanned_pdf(pages, codec=args.codec, encoded=enc)
         run = lambda: pipe.process_pdf(pdf_bytes, "bench", layout_priors=priors)
@@ -218,12 +228,12 @@ def main():
             "scaling": "weak",
             "vs_baseline": round(total_pages / dt / CPU_PROXY_PAGES_PER_S, 1),
             "dtype": "bf16" if use_gpu else "fp32-cpu-debug",
-            "data": (("synthetic 300-DPI A4 scanned PDF (rendered text + noise, %s page images); weights trained in-repo "
-                      "on this synthetic page family (train/page_trainer.py), detector boxes used as found" % args.codec)
+            "data": (("synthetic 300-DPI A4 scanned PDF (rendered text + noise; page images: %s); weights trained in-repo "
+                      "on this synthetic page family (train/page_trainer.py), detector boxes used as found" % images)
                      if trained else
-                     ("synthetic 300-DPI A4 scanned PDF (rendered text + noise, %s page images), random-init weights; "
+                     ("synthetic 300-DPI A4 scanned PDF (rendered text + noise; page images: %s), random-init weights; "
                       "recognizer fed the generator's ground-truth line boxes because a random-init detector "
-                      "finds none (detector + post-process still run on every page)" % args.codec))
+                      "finds none (detector + post-process still run on every page)" % images))
             if args.input == "pdf" else "synthetic decoded 300-DPI A4 rasters",
             "config": {
                 "model": ("DBNet-R18 (1344x960 det input) + CRNN (2xBiLSTM-256, h=48) + CTC greedy" if args.recognizer == "crnn"
@@ -236,6 +246,7 @@ def main():
                 "lines_per_page": round(lines_per_page, 1),
                 "batch_pages": args.batch_pages,
                 "input": args.input,
+                "page_images": images if args.input == "pdf" else "decoded rasters",
                 "p50_extract_latency_ms": round(1000.0 * (sorted(lat)[len(lat) // 2] if lat else dt / args.steps), 1),
                 "documents": "queued back to back through one engine pipeline" if stream_docs else "one at a time",
                 "lines_recognized": n_lines,

@@ -52,6 +52,7 @@ class Client:
 
 
 def run_doc(client, pdf_body, ctype, doc_id, poll=0.002):
+    """Upload, poll /check-status every ``poll`` seconds, fetch /result.  -> (latency, status, text, upload time)."""
     t0 = time.perf_counter()
     st, data = client.request("POST", "/extract", body=pdf_body, headers={"content-type": ctype})
     assert st == 200 and json.loads(data) == {"status": "ok"}, data
@@ -77,6 +78,8 @@ def main():
     ap.add_argument("--scan-docs", type=int, default=4)
     ap.add_argument("--burst-docs", type=int, default=32)
     ap.add_argument("--burst-pages", type=int, default=4)
+    ap.add_argument("--burst-rounds", type=int, default=6, help="documents each concurrent client submits, one after another")
+    ap.add_argument("--burst-poll-ms", type=float, default=10.0, help="status polling interval of the concurrent clients")
     ap.add_argument("--num-gpus", type=int, default=-1)
     ap.add_argument("--force-pool", action="store_true", help="use the worker-process pool even with one GPU")
     args = ap.parse_args()
@@ -131,20 +134,23 @@ def main():
     # ---- burst of small scans from concurrent clients
     small = synth.make_scanned_pdf([rendered[i % 10] for i in range(args.burst_pages)], codec="jpeg",
                                    encoded=[enc[i % 10] for i in range(args.burst_pages)])
-    lats = [0.0] * args.burst_docs
+    lats = [0.0] * (args.burst_docs * args.burst_rounds)
 
-    bodies = [body_for(small, f"burst-{i}") for i in range(args.burst_docs)]
+    bodies = [[body_for(small, f"burst-{i}-{r}") for r in range(args.burst_rounds)] for i in range(args.burst_docs)]
 
     def one(i):
-        lats[i] = run_doc(Client(args.port), *bodies[i], f"burst-{i}")[0]
+        c = Client(args.port)
+        for r in range(args.burst_rounds):
+            lats[i * args.burst_rounds + r] = run_doc(c, *bodies[i][r], f"burst-{i}-{r}", poll=args.burst_poll_ms / 1000.0)[0]
 
     t0 = time.perf_counter()
     ths = [threading.Thread(target=one, args=(i,)) for i in range(args.burst_docs)]
     [t.start() for t in ths]
     [t.join() for t in ths]
     wall = time.perf_counter() - t0
-    out["burst_small_scans"] = {"docs": args.burst_docs, "pages_each": args.burst_pages,
-                                "pages_per_s": round(args.burst_docs * args.burst_pages / wall, 1),
+    out["burst_small_scans"] = {"clients": args.burst_docs, "docs_per_client": args.burst_rounds, "pages_each": args.burst_pages,
+                                "poll_ms": args.burst_poll_ms,
+                                "pages_per_s": round(args.burst_docs * args.burst_rounds * args.burst_pages / wall, 1),
                                 "p50_s": round(float(np.percentile(lats, 50)), 3), "p95_s": round(float(np.percentile(lats, 95)), 3)}
     out["metrics_sample"] = [l for l in client.request("GET", "/metrics")[1].decode().splitlines()
                              if l.startswith(("ocr_pages_total", "ocr_documents_total", "ocr_batch_fill", "ocr_workers_alive"))]

@@ -15,110 +15,36 @@
 //
 // Output is the luma plane (gray) - all the OCR models consume.  Chroma blocks of
 // YCbCr files are entropy-decoded (to stay in sync) and discarded.
-// Files without restart markers / progressive files are decoded on the host
-// thread pool instead (ops/jpeg.py).
+//
+// Streams WITHOUT restart markers (what most scanners write) have no entry points, so they are decoded by
+// self-synchronisation (the property that a Huffman decoder started at a wrong bit falls into step with the true
+// code-word sequence after a few symbols):
+//   a. jpeg_sync_kernel      the scan is cut into 128-byte subsequences, one lane each.  Every lane decodes its
+//                            subsequence from a guessed state (code-word boundary, start of a block), then keeps
+//                            decoding into the following subsequences until its state at a subsequence end equals
+//                            the one already recorded there - from then on both paths are identical.  Lower lanes
+//                            overwrite higher ones, so within a 256-subsequence chunk everything follows the chunk's
+//                            first lane, which has itself fallen into step long before the chunk ends.
+//   b. jpeg_sync_seam_kernel one lane per chunk seam carries the end state of the previous chunk into the next one
+//                            until it meets the recorded path, in passes that repeat until nothing changes; lane 0
+//                            of the image starts from the real beginning, so by induction every recorded state is
+//                            then the true one.
+//   c. exclusive prefix sum of the blocks completed per subsequence (torch.cumsum) = where each lane writes.
+//   d. jpeg_sync_decode_kernel  every lane decodes its subsequence once more from its true start state and writes
+//                            dequantised AC coefficients and DC DIFFERENCES.
+//   e. prefix sum of the DC differences over the luma blocks in decode order, jpeg_dc_apply_kernel, then the IDCT.
+// Every bit is decoded about three times; in exchange a page yields ~10 000 independent lanes instead of one.
+// Progressive files and exotic sampling are decoded on the host thread pool (ops/jpeg.py).
 #include "common.h"
 
 #include <stdlib.h>
 
 #define JPEG_DEFAULT_SPREAD 1
-#define JPEG_LUT_BITS 10
-#define JPEG_LUT_SIZE (1 << JPEG_LUT_BITS)
-
-struct JpegTables {
-  uint16_t qt[3][64];
-  uint16_t lut[4][JPEG_LUT_SIZE];
-  int32_t maxcode[4][18];
-  int32_t valoff[4][17];
-  uint8_t vals[4][256];
-};
-static_assert(sizeof(JpegTables) == 3 * 64 * 2 + 4 * JPEG_LUT_SIZE * 2 + 4 * 18 * 4 + 4 * 17 * 4 + 4 * 256, "ABI");
-
-struct JpegImageDesc {
-  const uint8_t* data;        // JPEG stream (>= 16 readable bytes of slack after scan_end)
-  const uint32_t* seg_off;    // [n_segments] offsets into data
-  const JpegTables* tables;
-  int16_t* coef;              // [Hb * Wb * 64] luma coefficients, zero-filled by the caller
-  uint8_t* out;               // [Hb * 8, Wb * 8] gray
-  int32_t n_segments, restart_interval, mcus_x, total_mcus;
-  int32_t ncomp, hs0, vs0, scan_end;
-  int32_t Wb, Hb, pad0, pad1;
-};
-static_assert(sizeof(JpegImageDesc) == 88, "ABI");
+#include "jpeg_core.h"
 
 __constant__ uint8_t c_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                                      41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                      30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-
-struct BitReader {
-  const uint8_t* p;
-  const uint8_t* end;
-  uint64_t acc;   // MSB-aligned
-  int nbits;
-  bool hit_marker;
-
-  __device__ __forceinline__ void init(const uint8_t* s, const uint8_t* e) {
-    p = s; end = e; acc = 0; nbits = 0; hit_marker = false;
-  }
-  // guarantee >= 32 valid bits (zero-extended past the end of the segment)
-  __device__ __forceinline__ void refill() {
-    if (nbits > 32) return;
-    if (!hit_marker && p + 4 <= end) {
-      uint32_t w;
-      __builtin_memcpy(&w, p, 4);
-      uint32_t x = ~w;
-      if ((((x - 0x01010101u) & ~x) & 0x80808080u) == 0u) {  // no 0xFF byte among the four
-        uint32_t be = __builtin_bswap32(w);
-        acc |= (uint64_t)be << (32 - nbits);
-        nbits += 32;
-        p += 4;
-        return;
-      }
-    }
-    while (nbits <= 56) {
-      uint32_t b = 0;
-      if (!hit_marker && p < end) {
-        b = *p;
-        if (b == 0xFF) {
-          uint32_t b2 = (p + 1 < end) ? p[1] : 0xD9;
-          if (b2 == 0) p += 2;
-          else { hit_marker = true; b = 0; }
-        } else {
-          ++p;
-        }
-      }
-      acc |= (uint64_t)b << (56 - nbits);
-      nbits += 8;
-    }
-  }
-  __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)(acc >> (64 - n)); }
-  __device__ __forceinline__ void skip(int n) { acc <<= n; nbits -= n; }
-};
-
-__device__ __forceinline__ int huff_decode(BitReader& br, const uint16_t* lut, const JpegTables* __restrict__ tb, int t) {
-  uint32_t e = lut[br.peek(JPEG_LUT_BITS)];
-  if (e) {
-    br.skip(e >> 8);
-    return e & 0xff;
-  }
-  // slow path: codes of 11..16 bits (canonical decode)
-  int len = JPEG_LUT_BITS + 1;
-  int code = (int)br.peek(len);
-  while (len <= 16 && code > tb->maxcode[t][len]) {
-    ++len;
-    code = (int)br.peek(len);
-  }
-  if (len > 16) { br.skip(16); return 0; }
-  br.skip(len);
-  return tb->vals[t][(code + tb->valoff[t][len]) & 0xff];
-}
-
-__device__ __forceinline__ int receive_extend(BitReader& br, int s) {
-  if (s == 0) return 0;
-  int v = (int)br.peek(s);
-  br.skip(s);
-  return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
-}
 
 // `spread` = lanes per segment slot: only every spread-th lane decodes (1: all 64 lanes of a wave busy).  The decode
 // loops are data dependent, so a wave runs the union of its lanes' paths; fewer segments per wave cut that
@@ -187,6 +113,112 @@ __global__ __launch_bounds__(128) void jpeg_huffman_kernel(const JpegImageDesc* 
       }
     }
   }
+}
+
+#define JPEG_SYNC_LOAD_TABLES(NT)                                                                          \
+  __shared__ uint16_t s_lut[4][JPEG_LUT_SIZE];                                                             \
+  __shared__ uint16_t s_qt[64];                                                                            \
+  __shared__ uint8_t s_zz[64];                                                                             \
+  {                                                                                                        \
+    const int ntab = d.ncomp == 1 ? 2 : 4;                                                                 \
+    for (int i = threadIdx.x; i < ntab * JPEG_LUT_SIZE; i += NT) (&s_lut[0][0])[i] = (&d.tables->lut[0][0])[i]; \
+    if (threadIdx.x < 64) { s_qt[threadIdx.x] = d.tables->qt[0][threadIdx.x]; s_zz[threadIdx.x] = c_zigzag[threadIdx.x]; } \
+  }                                                                                                        \
+  __syncthreads();
+
+__global__ __launch_bounds__(JPEG_SUB_CHUNK) void jpeg_sync_kernel(const JpegImageDesc* __restrict__ descs) {
+  const JpegImageDesc d = descs[blockIdx.y];
+  const int j0 = blockIdx.x * JPEG_SUB_CHUNK;
+  if (j0 >= d.n_sub) return;
+  JPEG_SYNC_LOAD_TABLES(JPEG_SUB_CHUNK)
+  __shared__ uint32_t s_state[JPEG_SUB_CHUNK];
+  __shared__ int s_cnt[JPEG_SUB_CHUNK];
+  __shared__ int s_stuff[JPEG_SUB_CHUNK];
+  const int tid = threadIdx.x, j = j0 + tid;
+  const int n_here = min(JPEG_SUB_CHUNK, d.n_sub - j0);
+  const bool valid = tid < n_here;
+  s_stuff[tid] = valid ? sub_stuffing(d, j) : 0;
+  __syncthreads();
+  SubState st = {0, 0, 0};
+  if (valid) {
+    s_cnt[tid] = sub_decode<false>(d, j, st, s_stuff[tid], 0, s_lut, s_qt, s_zz);
+    s_state[tid] = sub_pack(st);
+  }
+  __syncthreads();
+  bool active = valid;
+  for (int r = 1; r < JPEG_SUB_CHUNK; ++r) {
+    const int t = tid + r;
+    const bool go = active && t < n_here;
+    uint32_t mine = 0;
+    int cnt = 0;
+    if (go) {
+      cnt = sub_decode<false>(d, j + r, st, s_stuff[t], 0, s_lut, s_qt, s_zz);
+      mine = sub_pack(st);
+    }
+    const bool same = go && s_state[t] == mine;
+    __syncthreads();                                   // every comparison of this round is done before any write
+    if (go) { s_state[t] = mine; s_cnt[t] = cnt; }     // the lower lane's path is the better one, merged or not
+    active = go && !same;
+    if (!__syncthreads_or(active ? 1 : 0)) break;
+  }
+  if (valid) {
+    d.sub_state[j] = s_state[tid];
+    d.sub_count[j] = s_cnt[tid];
+  }
+}
+
+// Seams between chunks, one workgroup per image, one lane per seam (chunk c >= 1): walk into chunk c from the end
+// state of chunk c-1 until the recorded path is met.  A pass in which some lane rewrote states may have invalidated
+// the start of the following seam (only when a path crosses a whole chunk without merging: blank pages, whose
+// identical code words never resynchronise), so passes repeat until one changes nothing - at most once per chunk,
+// in which case the lanes have together done one serial decode of the scan.
+__global__ __launch_bounds__(256) void jpeg_sync_seam_kernel(const JpegImageDesc* __restrict__ descs) {
+  const JpegImageDesc d = descs[blockIdx.x];
+  const int n_chunks = (d.n_sub + JPEG_SUB_CHUNK - 1) / JPEG_SUB_CHUNK;
+  if (n_chunks <= 1) return;
+  JPEG_SYNC_LOAD_TABLES(256)
+  for (int pass = 0; pass < n_chunks; ++pass) {
+    int changed = 0;
+    for (int c = 1 + (int)threadIdx.x; c < n_chunks; c += 256) {
+      const int j0 = c * JPEG_SUB_CHUNK;
+      SubState st = sub_unpack(__hip_atomic_load(d.sub_state + j0 - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      const int n_here = min(JPEG_SUB_CHUNK, d.n_sub - j0);
+      for (int t = 0; t < n_here; ++t) {
+        const int cnt = sub_decode<false>(d, j0 + t, st, sub_stuffing(d, j0 + t), 0, s_lut, s_qt, s_zz);
+        const uint32_t mine = sub_pack(st);
+        if (d.sub_state[j0 + t] == mine) { d.sub_count[j0 + t] = cnt; break; }
+        __hip_atomic_store(d.sub_state + j0 + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        d.sub_count[j0 + t] = cnt;
+        changed = 1;
+      }
+    }
+    __threadfence();
+    if (!__syncthreads_or(changed)) break;
+  }
+}
+
+__global__ __launch_bounds__(128) void jpeg_sync_decode_kernel(const JpegImageDesc* __restrict__ descs) {
+  const JpegImageDesc d = descs[blockIdx.y];
+  if ((int)(blockIdx.x * 128) >= d.n_sub) return;
+  JPEG_SYNC_LOAD_TABLES(128)
+  const int j = blockIdx.x * 128 + threadIdx.x;
+  if (j >= d.n_sub) return;
+  SubState st = j == 0 ? SubState{0, 0, 0} : sub_unpack(d.sub_state[j - 1]);
+  sub_decode<true>(d, j, st, sub_stuffing(d, j), d.sub_off[j], s_lut, s_qt, s_zz);
+}
+
+// dcabs: [n luma blocks] running sum of the DC differences (decode order).  One lane per luma block.
+__global__ __launch_bounds__(256) void jpeg_dc_apply_kernel(const JpegImageDesc* __restrict__ descs, const int32_t* const* dcabs) {
+  const JpegImageDesc d = descs[blockIdx.y];
+  const int yblocks = d.hs0 * d.vs0;
+  const long long n_luma = (long long)d.total_mcus * yblocks;
+  const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (o >= n_luma) return;
+  const int mcu = (int)(o / yblocks), b = (int)(o - (long long)mcu * yblocks);
+  const int my = mcu / d.mcus_x, mx = mcu - my * d.mcus_x;
+  const int bx = mx * d.hs0 + (b % d.hs0), by = my * d.vs0 + (b / d.hs0);
+  const int v = dcabs[blockIdx.y][o] * (int)d.tables->qt[0][0];
+  d.coef[((long long)by * d.Wb + bx) * 64] = (int16_t)max(-32768, min(32767, v));
 }
 
 // 1-D 8-point inverse DCT (direct form): out[x] = 1/2 * sum_u c(u) in[u] cos((2x+1) u pi / 16)
@@ -259,6 +291,38 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const JpegImageDesc* __r
     uint8_t* o = d.out + ((long long)(by * 8 + r) * d.Wb + bx) * 8;
     *reinterpret_cast<u32x2*>(o) = u32x2{w0, w1};
   }
+}
+
+// Restart-less streams, first half: synchronisation (kernels a and b).  max_sub: largest n_sub of the batch.
+extern "C" int dlamd_jpeg_sync(const void* descs, int n, int max_sub, hipStream_t stream) {
+  if (n <= 0) return 0;
+  if (n > 65535 || max_sub <= 0) return -1;
+  const int chunks = (max_sub + JPEG_SUB_CHUNK - 1) / JPEG_SUB_CHUNK;
+  hipLaunchKernelGGL(jpeg_sync_kernel, dim3(chunks, n), dim3(JPEG_SUB_CHUNK), 0, stream, (const JpegImageDesc*)descs);
+  if (chunks > 1) hipLaunchKernelGGL(jpeg_sync_seam_kernel, dim3(n), dim3(256), 0, stream, (const JpegImageDesc*)descs);
+  return DLAMD_CHECK_LAUNCH();
+}
+
+// Second half, after the caller has turned sub_count into sub_off: coefficient decode (kernel d).
+extern "C" int dlamd_jpeg_sync_decode(const void* descs, int n, int max_sub, hipStream_t stream) {
+  if (n <= 0) return 0;
+  if (n > 65535 || max_sub <= 0) return -1;
+  hipLaunchKernelGGL(jpeg_sync_decode_kernel, dim3((max_sub + 127) / 128, n), dim3(128), 0, stream, (const JpegImageDesc*)descs);
+  return DLAMD_CHECK_LAUNCH();
+}
+
+// Last part, after the caller's prefix sum over dcdiff: absolute DC values into the coefficient planes, then the IDCT.
+// dcabs: device array of n pointers.  max_luma / max_blocks: maxima over the batch.
+extern "C" int dlamd_jpeg_sync_finish(const void* descs, const void* dcabs, int n, long long max_luma, long long max_blocks,
+                                      hipStream_t stream) {
+  if (n <= 0) return 0;
+  if (n > 65535 || max_luma <= 0 || max_blocks <= 0) return -1;
+  const long long g1 = (max_luma + 255) / 256, g2 = (max_blocks + 31) / 32;
+  if (g1 > 0x7fffffffLL || g2 > 0x7fffffffLL) return -2;
+  hipLaunchKernelGGL(jpeg_dc_apply_kernel, dim3((unsigned)g1, n), dim3(256), 0, stream, (const JpegImageDesc*)descs,
+                     (const int32_t* const*)dcabs);
+  hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)g2, n), dim3(256), 0, stream, (const JpegImageDesc*)descs);
+  return DLAMD_CHECK_LAUNCH();
 }
 
 // descs: device array of n JpegImageDesc; max_segments / max_blocks: maxima over the batch (grid sizing).

@@ -31,7 +31,7 @@ struct JpegInfo {
   int32_t blocks_per_mcu;
   int32_t n_segments;
   int64_t scan_off, scan_len;  // entropy-coded data inside the stream
-  int32_t supported;           // 1 when the GPU decoder can take it
+  int32_t supported;           // GPU decoder: 0 no, 1 one lane per restart segment, 2 self-synchronising (no restarts)
   int32_t pad;
 };
 
@@ -218,7 +218,15 @@ inline int scan_jpeg(const uint8_t* d, size_t n, JpegInfo* info, JpegTables* tab
       } else {
         seg_ok = info->n_segments == 1;
       }
-      info->supported = (!info->progressive && info->precision == 8 && all_in_scan && chroma_ok && tables_ok && seg_ok) ? 1 : 0;
+      const bool base_ok = !info->progressive && info->precision == 8 && all_in_scan && chroma_ok && tables_ok && seg_ok &&
+                           info->scan_len > 0 && (long long)info->scan_off + info->scan_len < (1LL << 31);
+      // One lane per restart segment needs many segments to fill a GPU; a restart-less scan goes through the
+      // self-synchronising decoder; a large image cut into a handful of long segments stays on the host.
+      info->supported = 0;
+      if (base_ok) {
+        if (info->restart_interval == 0) info->supported = 2;
+        else if (info->n_segments >= 32 || total_mcus <= 4096) info->supported = 1;
+      }
       if (tables && tables_ok) {
         memset(tables, 0, sizeof(*tables));
         for (int c = 0; c < info->ncomp && c < 3; ++c) memcpy(tables->qt[c], qt[info->tq[c]], sizeof(uint16_t) * 64);

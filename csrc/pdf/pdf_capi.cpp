@@ -9,6 +9,7 @@
 
 #include "ccitt_fax.h"
 #include "jpeg_scan.h"
+#include "jpeg_sync_host.h"
 #include "pdf_content.h"
 
 using namespace dlpdf;
@@ -508,6 +509,15 @@ int dljpeg_sizes(int* info_size, int* tables_size) {
   *info_size = (int)sizeof(dljpeg::JpegInfo);
   *tables_size = (int)sizeof(dljpeg::JpegTables);
   return 0;
+}
+
+// Host emulation of the GPU's self-synchronising decode (tests).  out: gray plane [mcus_y*vs0*8][mcus_x*hs0*8].
+int dljpeg_decode_sync_host(const uint8_t* d, size_t n, uint8_t* out, size_t cap, dljpeg::SyncStats* stats) {
+  try {
+    return dljpeg::decode_sync_host(d, n, out, cap, stats);
+  } catch (...) {
+    return -100;
+  }
 }
 
 // seg_offsets may be null (count only).  Returns 0, or < 0 on malformed input; info->n_segments holds the

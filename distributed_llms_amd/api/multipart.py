@@ -160,6 +160,7 @@ class StreamingForm:
         self._in_file = False
         self._data_start = 0
         self._hashed_to = 0
+        self._scanned_to = 0             # every byte before this has been searched for the closing delimiter
         self._file_span = None           # (start, end) of the hashed file part once its closing delimiter is seen
 
     def feed(self, chunk: bytes) -> None:
@@ -209,8 +210,9 @@ class StreamingForm:
             self._pos = nxt + 2
         if self._in_file:
             tail = len(delim) + 2
-            scan_from = max(self._data_start, self._hashed_to - tail)
+            scan_from = max(self._data_start, self._scanned_to - tail)
             end = buf.find(b"\r\n" + delim, scan_from, n)
+            self._scanned_to = n
             safe = end if end >= 0 else n - tail
             if end >= 0:
                 self._file_span = (self._data_start, end)

@@ -96,6 +96,9 @@ def _declare(l: ctypes.CDLL) -> None:
     sig("dlamd_adamw", [vp, vp, vp, vp, vp, ll, f, f, f, f, f, f, f, vp, vp])
     sig("dlamd_sumsq", [vp, ll, vp, vp])
     sig("dlamd_jpeg_decode", [vp, i, i, ll, vp])
+    sig("dlamd_jpeg_sync", [vp, i, i, vp])
+    sig("dlamd_jpeg_sync_decode", [vp, i, i, vp])
+    sig("dlamd_jpeg_sync_finish", [vp, vp, i, ll, ll, vp])
     sig("dlamd_lstm_train_fwd", [vp, vp, vp, vp, vp, vp, i, i, i, i, vp])
     sig("dlamd_lstm_train_bwd", [vp, vp, vp, vp, vp, vp, i, i, i, i, vp])
     sig("dlamd_dar_create", [i, i, ll, i, vp])

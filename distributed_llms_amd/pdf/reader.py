@@ -57,6 +57,12 @@ class JpegInfo(ctypes.Structure):
                 ("scan_len", ctypes.c_int64), ("supported", ctypes.c_int32), ("pad", ctypes.c_int32)]
 
 
+class JpegSyncStats(ctypes.Structure):
+    _fields_ = [("n_sub", ctypes.c_int32), ("max_rounds", ctypes.c_int32), ("max_seam_steps", ctypes.c_int32),
+                ("blocks_decoded", ctypes.c_int32), ("seam_passes", ctypes.c_int32), ("pad", ctypes.c_int32),
+                ("sub_decodes", ctypes.c_int64)]
+
+
 # byte size of the device-side table blob (struct JpegTables in csrc/pdf/jpeg_scan.h)
 JPEG_TABLES_BYTES = 3 * 64 * 2 + 4 * (1 << JPEG_LUT_BITS) * 2 + 4 * 18 * 4 + 4 * 17 * 4 + 4 * 256
 
@@ -93,6 +99,7 @@ def lib() -> ctypes.CDLL:
             l.dlpdf_classify.argtypes = [vp, ctypes.POINTER(_Classify)]
             l.dljpeg_sizes.argtypes = [ctypes.POINTER(i), ctypes.POINTER(i)]
             l.dljpeg_scan.argtypes = [vp, sz, ctypes.POINTER(JpegInfo), vp, vp, i]
+            l.dljpeg_decode_sync_host.argtypes = [vp, sz, vp, sz, ctypes.POINTER(JpegSyncStats)]
             a, b = ctypes.c_int(), ctypes.c_int()
             l.dljpeg_sizes(ctypes.byref(a), ctypes.byref(b))
             if a.value != ctypes.sizeof(JpegInfo) or b.value != JPEG_TABLES_BYTES:
@@ -156,7 +163,13 @@ class JpegScan:
 
     @property
     def gpu_decodable(self) -> bool:
-        return bool(self.info.supported)
+        return self.info.supported in (1, 2)
+
+    @property
+    def self_synchronising(self) -> bool:
+        """No restart markers: the GPU decodes the scan in 128-byte subsequences that find the code-word boundaries
+        by themselves (ops/jpeg.py)."""
+        return self.info.supported == 2
 
 
 def scan_jpeg(data, max_segments: int = 1 << 20) -> JpegScan:
@@ -177,6 +190,23 @@ def scan_jpeg(data, max_segments: int = 1 << 20) -> JpegScan:
         lib().dljpeg_scan(buf.ctypes.data, buf.size, ctypes.byref(info), tables.ctypes.data, segs.ctypes.data,
                           info.n_segments)
     return JpegScan(info, tables, segs[: info.n_segments].copy())
+
+
+def decode_jpeg_sync_host(data) -> Tuple[np.ndarray, JpegSyncStats]:
+    """Serial host emulation of the GPU's self-synchronising decode of a restart-less baseline JPEG
+    (csrc/pdf/jpeg_sync_host.h).  Returns the gray plane [height, width] and the synchronisation statistics."""
+    buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    sc = scan_jpeg(buf)
+    if not sc.self_synchronising:
+        raise PdfError("not a restart-less baseline JPEG")
+    i = sc.info
+    H, W = i.mcus_y * i.vs[0] * 8, i.mcus_x * i.hs[0] * 8
+    out = np.empty((H, W), dtype=np.uint8)
+    stats = JpegSyncStats()
+    rc = lib().dljpeg_decode_sync_host(buf.ctypes.data, buf.size, out.ctypes.data, out.size, ctypes.byref(stats))
+    if rc != 0:
+        raise PdfError(f"self-synchronising decode failed (code {rc})")
+    return out[: i.height, : i.width], stats
 
 
 class PdfDocument:

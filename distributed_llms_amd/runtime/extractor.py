@@ -150,7 +150,13 @@ def make_extractor(settings, image_writer: Optional[LocalFileWriter] = None) -> 
 
     from .engine import EngineConfig, OcrEngine
 
-    ngpu_visible = torch.cuda.device_count()
+    # counted from the environment / sysfs: a front end that only supervises GPU worker processes must not bring the
+    # GPU runtime up itself (it forks and execs those workers, and every respawn)
+    from ..api.serve import count_gpus
+
+    ngpu_visible = count_gpus() if settings.num_gpus != 0 else 0
+    if ngpu_visible == 0 and settings.num_gpus != 0 and torch.cuda.is_available():
+        ngpu_visible = torch.cuda.device_count()        # no sysfs view of the devices (containers): ask the runtime
     want = settings.num_gpus if settings.num_gpus >= 0 else ngpu_visible
     ids = list(range(ngpu_visible))
     if getattr(settings, "gpu_ids", None):      # OCR_GPU_IDS: the subset of devices this front end drives

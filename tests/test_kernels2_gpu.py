@@ -72,17 +72,98 @@ def test_jpeg_color_luma_and_batch():
         assert d.max() <= 3 and d.mean() < 0.5, (d.max(), d.mean())
 
 
-def test_jpeg_without_restart_markers_is_host_only():
-    pg, _ = synth.render_page(1, size=(200, 120), font_px=12, margin=10)
-    st = _jpeg(pg, quality=80)
+def _blocks_ok(t):
+    cnt, expect = t._dlamd_blocks
+    return int(cnt.sum()) == expect
+
+
+@pytest.mark.parametrize("case", [
+    dict(size=(200, 120), quality=80),                      # 2 chunks of subsequences at most
+    dict(size=(1240, 1754), quality=85),                    # 150-DPI page: ~3000 subsequences, a dozen chunk seams
+    dict(size=(1240, 1754), quality=95, optimize=True),     # image-specific Huffman tables, long codes
+    dict(size=(333, 211), quality=40),                      # ragged MCU edges, many EOB-only blocks
+])
+def test_jpeg_without_restart_markers_self_synchronises(case):
+    case = dict(case)
+    W, H = case.pop("size")
+    pg, _ = synth.render_page(1, size=(W, H), font_px=14 if W < 1000 else 22, margin=20, noise=3.0)
+    st = _jpeg(pg, **case)
     sc = reader.scan_jpeg(st)
-    # a single segment is still decodable (one lane), just not parallel
-    assert sc.info.n_segments == 1 and sc.gpu_decodable
+    assert sc.info.restart_interval == 0 and sc.gpu_decodable and sc.self_synchronising
     out = J.decode_jpeg_batch_gpu([st], [sc], torch.device(DEV))[0]
+    torch.cuda.synchronize()
+    assert _blocks_ok(out)
     ref = J.decode_jpeg_host(st).astype(np.int32)
-    assert np.abs(out.cpu().numpy().astype(np.int32) - ref).max() <= 2
+    d = np.abs(out.cpu().numpy().astype(np.int32) - ref)
+    assert d.max() <= 2 and d.mean() < 0.3, (d.max(), d.mean())
+    # the host emulation of the same pipeline agrees with the GPU bit for bit up to IDCT rounding
+    emu, _ = reader.decode_jpeg_sync_host(st)
+    assert np.abs(out.cpu().numpy().astype(np.int32) - emu.astype(np.int32)).max() <= 1
     prog = _jpeg(pg, quality=80, progressive=True)
     assert not reader.scan_jpeg(prog).gpu_decodable
+
+
+def test_jpeg_blank_page_never_resynchronises_but_decodes():
+    # identical code words block after block: a lane started at a wrong phase never meets the true path, so the
+    # chunk rounds run to their bound and the seam passes repeat once per chunk
+    blank = np.full((1754, 1240), 255, dtype=np.uint8)
+    blank[900:930, 100:700] = 0
+    st = _jpeg(blank, quality=85)
+    sc = reader.scan_jpeg(st)
+    out = J.decode_jpeg_batch_gpu([st], [sc], torch.device(DEV))[0]
+    torch.cuda.synchronize()
+    assert _blocks_ok(out)
+    ref = J.decode_jpeg_host(st).astype(np.int32)
+    assert np.abs(out.cpu().numpy().astype(np.int32) - ref).max() <= 2
+
+
+def test_jpeg_mixed_batch_colour_and_restart_kinds():
+    rng = np.random.default_rng(5)
+    pg, _ = synth.render_page(2, size=(620, 877), font_px=14, margin=20, noise=3.0)
+    rgb = np.stack([pg, pg // 2 + 60, 255 - pg], axis=-1)
+    streams = [
+        _jpeg(pg, quality=85),                                   # gray, no restarts
+        _jpeg(pg, quality=85, restart_marker_blocks=8),          # gray, restart segments
+        _jpeg(rgb, quality=85),                                  # 4:2:0, no restarts
+        _jpeg(rgb, quality=85, subsampling=0),                   # 4:4:4, no restarts
+        _jpeg(rng.integers(0, 255, (96, 160), dtype=np.uint8), quality=92),   # noise: long codes, many stuffed bytes
+    ]
+    scans = [reader.scan_jpeg(s) for s in streams]
+    assert [s.self_synchronising for s in scans] == [True, False, True, True, True]
+    outs = J.decode_jpeg_batch_gpu(streams, scans, torch.device(DEV))
+    torch.cuda.synchronize()
+    from PIL import Image
+    import io
+
+    for st, o in zip(streams, outs):
+        im = Image.open(io.BytesIO(st.tobytes()))
+        im.draft("L", im.size)
+        y = np.asarray(im).astype(np.int32)
+        d = np.abs(o.cpu().numpy().astype(np.int32) - y)
+        assert d.max() <= 3 and d.mean() < 0.5, (d.max(), d.mean())
+
+
+def test_jpeg_a4_page_without_restart_markers_decodes_fast():
+    """A 300-DPI A4 scan as scanners write it (no DRI) must not fall back to ~55 ms of libjpeg on the host."""
+    pg, _ = synth.render_page(7, size=(2480, 3508), font_px=40, margin=120, noise=3.0)
+    st = _jpeg(pg, quality=85)
+    sc = reader.scan_jpeg(st)
+    assert sc.self_synchronising
+    dev = torch.device(DEV)
+    for _ in range(2):
+        out = J.decode_jpeg_batch_gpu([st], [sc], dev)[0]
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = J.decode_jpeg_batch_gpu([st], [sc], dev)[0]
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    assert _blocks_ok(out)
+    ref = J.decode_jpeg_host(st).astype(np.int32)
+    assert np.abs(out.cpu().numpy().astype(np.int32) - ref).max() <= 2
+    print(f"no-RST A4 decode: {ms:.2f} ms, {st.size / 1e6:.2f} MB")
+    assert ms < 20.0, ms
 
 
 def test_resample_pitched_source():

@@ -291,3 +291,64 @@ def test_process_pdfs_streams_documents_and_matches_one_at_a_time():
         assert [p.page_index for p in got.pages] == [p.page_index for p in want.pages]
         assert all(p.doc_id == did for p in got.pages)
     pipe.close()
+
+
+def _jpeg_bytes(arr, **kw):
+    from PIL import Image
+
+    b = io.BytesIO()
+    Image.fromarray(arr).save(b, format="JPEG", **kw)
+    return np.frombuffer(b.getvalue(), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("case", [
+    dict(kind="text", size=(620, 877), quality=85),
+    dict(kind="text", size=(620, 877), quality=95, optimize=True),
+    dict(kind="noise", size=(312, 200), quality=90),          # long codes, stuffed 0xFF bytes at subsequence edges
+    dict(kind="rgb", size=(320, 240), quality=85),            # 4:2:0: six blocks per MCU, two table pairs
+    dict(kind="rgb", size=(320, 240), quality=85, subsampling=0),
+    dict(kind="blank", size=(2480, 3508), quality=85),        # never resynchronises: bounded rounds, repeated seam passes
+])
+def test_restartless_jpeg_self_synchronising_decode_matches_libjpeg(case):
+    """The pipeline the GPU runs for scans without restart markers (guessed-state subsequence decode, merge rounds,
+    seam passes, two prefix sums), executed serially on the host from the same source."""
+    from PIL import Image
+
+    case = dict(case)
+    kind = case.pop("kind")
+    W, H = case.pop("size")
+    rng = np.random.default_rng(1)
+    if kind == "text":
+        img, _ = synth.render_page(4, size=(W, H), font_px=14, margin=20, noise=3.0)
+    elif kind == "noise":
+        img = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    elif kind == "blank":
+        img = np.full((H, W), 255, dtype=np.uint8)
+        img[40:60, 100:900] = 0
+    else:
+        g, _ = synth.render_page(4, size=(W, H), font_px=12, margin=10)
+        img = np.stack([g, g // 2 + 60, 255 - g], axis=-1)
+    st = _jpeg_bytes(img, **case)
+    sc = reader.scan_jpeg(st)
+    assert sc.gpu_decodable and sc.self_synchronising and sc.info.n_segments == 1
+    got, stats = reader.decode_jpeg_sync_host(st)
+    assert stats.blocks_decoded == sc.info.mcus_x * sc.info.mcus_y * sc.info.blocks_per_mcu
+    im = Image.open(io.BytesIO(st.tobytes()))
+    im.draft("L", im.size)
+    ref = np.asarray(im).astype(np.int32)
+    d = np.abs(got.astype(np.int32) - ref)
+    assert d.max() <= 3 and d.mean() < 0.5, (d.max(), d.mean())
+    if kind == "blank":
+        assert stats.seam_passes > 1 and stats.max_rounds == 255
+    elif kind == "text":
+        # every lane falls into step within a few subsequences: ~2-3 decodes of each bit in total
+        assert stats.max_rounds <= 24 and stats.sub_decodes <= 4 * stats.n_sub
+
+
+def test_jpeg_routing_by_restart_structure():
+    img, _ = synth.render_page(4, size=(1240, 1754), font_px=22, margin=40)
+    a = reader.scan_jpeg(_jpeg_bytes(img, quality=80))
+    b = reader.scan_jpeg(_jpeg_bytes(img, quality=80, restart_marker_blocks=62))
+    c = reader.scan_jpeg(_jpeg_bytes(img, quality=80, restart_marker_rows=40))      # 6 long segments: host
+    d = reader.scan_jpeg(_jpeg_bytes(img, quality=80, progressive=True))
+    assert (a.info.supported, b.info.supported, c.info.supported, d.info.supported) == (2, 1, 0, 0)
