@@ -110,7 +110,7 @@ def main():
     # ---- config 2: 100-page scans
     pages_truth = [synth.render_page(i) for i in range(10)]
     rendered = [p for p, _ in pages_truth]
-    enc = [synth.encode_page_jpeg(p) for p in rendered]
+    enc = [synth.encode_page_jpeg(p, restart_blocks=0) for p in rendered]     # as scanners write them: no restart markers
     n = args.scan_pages
     scan = synth.make_scanned_pdf([rendered[i % 10] for i in range(n)], codec="jpeg", encoded=[enc[i % 10] for i in range(n)])
     res = [run_doc(client, *body_for(scan, f"scan-{i}"), f"scan-{i}") for i in range(args.scan_docs)]
