@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Flagship benchmark: pages/sec on synthetic 300-DPI A4 scanned PDFs (BASELINE.json configs 2 and 3).
+"""Flagship benchmark: pages/sec on synthetic 300-DPI A4 scanned PDFs (the scanned-document configurations of the
+reference's workload: one 100-page scan, and a corpus of them with dynamic batching).
 
 One *step* = one 100-page scanned PDF document taken from PDF bytes to per-page
 text on one GPU: PDF parse -> page image decode -> raster-to-tensor -> DBNet ->
@@ -7,7 +8,7 @@ DB post-process -> line crops -> CRNN -> CTC greedy decode -> strings.
 The K documents of the timed region are queued back to back through the engine
 (DocumentPipeline.process_pdfs): page batches never mix documents, but the
 two-stream pipeline is not drained between documents - the way a worker with a
-queue of uploads runs (BASELINE config 3 is a 10k-page corpus).  All K documents
+queue of uploads runs (the corpus configuration is 10k pages).  All K documents
 are extracted completely inside the timed region.  --sequential finishes each
 document before the next starts; the latency of a single document with nothing
 else in flight is measured before the timed region and reported as
@@ -18,8 +19,12 @@ scaling: 100 pages per GPU per step); the timed region is bracketed by a
 barrier + device synchronise on both sides and the per-rank times are
 MAX-reduced.
 
-The pages are synthetic (rendered text + scanner noise), as BASELINE.json
-prescribes.  No public checkpoint is reachable offline, so the weights are the
+--via-pool measures the product path instead: rank 0 is a front end that drives
+runtime.workers.WorkerPool (one engine process per GPU, dynamic batching, page
+sharding) with N documents in flight per step; the other ranks of a torchrun
+launch only take part in the barriers and never touch a GPU.
+
+The pages are synthetic (rendered text + scanner noise).  No public checkpoint is reachable offline, so the weights are the
 ones this repository trains itself on that page family (train/page_trainer.py,
 shipped under weights/): the detector finds the lines, the recognizer reads
 them, and the character error rate of the timed output against the generator's
@@ -46,7 +51,7 @@ import numpy as np
 import torch
 
 
-# the reference publishes no number and its engine cannot be installed offline; the comparison
+# The reference publishes no number and its engine cannot be installed offline; the comparison
 # point is the CPU proxy (same graphs, torch CPU eager, process pool of 8 on 8 vCPU): 0.84 pages/s.
 CPU_PROXY_PAGES_PER_S = 0.84
 
@@ -77,11 +82,95 @@ def parse_args():
     ap.add_argument("--recognizer", choices=["crnn", "trocr"], default="crnn",
                     help="trocr: TrOCR-base-sized ViT + decoder (BASELINE config 4; random-init, generator line boxes)")
     ap.add_argument("--trocr-tokens", type=int, default=32)
+    ap.add_argument("--via-pool", action="store_true",
+                    help="drive runtime.workers.WorkerPool (the service's multi-GPU back end) from rank 0 instead of one "
+                         "in-process engine per rank")
     return ap.parse_args()
+
+
+def main_via_pool(args):
+    """Product path: one front end (rank 0) + one engine worker process per GPU.  A step = N documents of
+    --pages-per-doc pages in flight at once (weak scaling: one document per GPU per step); the pool shards them over
+    the workers and its engine loops batch pages across documents."""
+    import torch.distributed as dist
+    from concurrent.futures import ThreadPoolExecutor
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    n = max(world, args.gpus)
+    if world > 1:
+        dist.init_process_group("gloo")      # CPU tensors only; ranks > 0 never initialise a GPU
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    out = None
+    if rank == 0:
+        from distributed_llms_amd.api.serve import count_gpus
+        from distributed_llms_amd.pdf import synth
+        from distributed_llms_amd.runtime.extractor import PoolExtractor
+        from distributed_llms_amd.runtime.workers import WorkerPool
+
+        use_gpu = not args.cpu and count_gpus() > 0          # counted without bringing the GPU runtime up here
+        size = synth.A4_300DPI if use_gpu else (248, 350)
+        cfg = dict(max_batch_pages=args.batch_pages, use_hip_graphs=not args.no_graphs)
+        if not use_gpu:
+            cfg.update(det_limit_side=160, rec_max_width=256, rec_width_quantum=64)
+        spec = {"model": "full" if use_gpu else "tiny", "cfg": cfg, "weights_dir": args.weights, "recognizer": args.recognizer}
+        devices = [f"cuda:{i}" for i in range(n)] if use_gpu else ["cpu"] * n
+        n_dist = min(args.distinct_pages, args.pages_per_doc)
+        rendered = [synth.render_page(i, size=size, font_px=42 if use_gpu else 10, margin=220 if use_gpu else 16)
+                    for i in range(n_dist)]
+        enc_d = [synth.encode_page_jpeg(rendered[i][0], restart_blocks=args.restart_blocks) for i in range(n_dist)]
+        pdf = synth.make_scanned_pdf([rendered[i % n_dist][0] for i in range(args.pages_per_doc)], codec="jpeg",
+                                     encoded=[enc_d[i % n_dist] for i in range(args.pages_per_doc)])
+        pool = WorkerPool(devices, spec, max_wait_ms=3.0).start()
+        ext = PoolExtractor(pool)
+        try:
+            with ThreadPoolExecutor(max_workers=2 * n) as tp:
+                def step(tag):
+                    docs = list(tp.map(lambda k: ext.extract_document(pdf, f"{tag}-{k}"), range(n)))
+                    assert all(len(d.pages) == args.pages_per_doc for d in docs)
+                    return sum(len(p.lines) for d in docs for p in d.pages)
+
+                for w in range(args.warmup):
+                    step(f"warm{w}")
+                barrier()
+                t0 = time.perf_counter()
+                n_lines = sum(step(f"bench{k}") for k in range(args.steps))
+                dt = time.perf_counter() - t0
+                barrier()
+            total_pages = args.steps * args.pages_per_doc * n
+            out = {
+                "metric": "pages/sec (whole node) on 300-DPI A4 scans", "value": round(total_pages / dt, 3), "unit": "pages/s",
+                "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": round(total_pages / dt / CPU_PROXY_PAGES_PER_S, 1),
+                "dtype": "bf16" if use_gpu else "fp32-cpu-debug",
+                "data": "synthetic 300-DPI A4 scanned PDF (rendered text + noise; page images: gray JPEG q85 %s)" % (
+                    "without restart markers" if args.restart_blocks == 0 else f"restart every {args.restart_blocks} MCUs"),
+                "config": {"model": "DBNet-R18 + CRNN + CTC greedy", "global_batch": args.pages_per_doc * n,
+                           "seq_len": 640 if use_gpu else 64, "parallelism": f"pool{n}",
+                           "pages_per_step_per_gpu": args.pages_per_doc, "page_px": list(size),
+                           "documents": f"{n} in flight per step through WorkerPool (front end + one engine process per GPU, "
+                                        "dynamic batching, page sharding)",
+                           "lines_recognized": n_lines, "pool": {k: v for k, v in pool.describe().items() if k != "worker_stats"}},
+            }
+        finally:
+            pool.stop()
+    else:
+        barrier()
+        barrier()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
     args = parse_args()
+    if args.via_pool:
+        return main_via_pool(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Recognizer training benchmark (BASELINE config 5): CRNN + CTC on synthetic line crops, DP over RCCL.
+"""Recognizer training benchmark (the reference workload's fine-tuning configuration): CRNN + CTC on synthetic line crops, DP over RCCL.
 
     python bench/train_bench.py --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 bench/train_bench.py
@@ -24,6 +24,7 @@ from distributed_llms_amd.train.trainer import CTCTrainer, TrainConfig
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1, help="launcher contract: number of ranks (informational)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
@@ -60,10 +61,13 @@ def main():
             "metric": "recognizer training samples/sec (CTC, synthetic line crops)",
             "value": round(args.steps * args.batch * env.world / dt, 2), "unit": "samples/s",
             "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "data": "synthetic rendered line crops, pre-rendered outside the timed region; random-init weights",
             "allreduce_wait_ms_per_step": round(1e3 * tr.comm_time / args.steps, 3),
             "grad_bytes_per_step": n_params * 4, "buckets": len(tr.ddp.flat.buckets), "dp_mode": args.mode,
             "final_loss": round(loss, 4), "dtype": "bf16 autocast, fp32 master" if env.device.type == "cuda" else "fp32",
             "config": {"model": "CRNN", "params": n_params, "per_gpu_batch": args.batch, "width": args.width,
+                       "global_batch": args.batch * env.world, "seq_len": args.width // 4,
                        "parallelism": f"dp{env.world}"},
         }), flush=True)
     comm.shutdown()

@@ -21,6 +21,8 @@ import time
 from concurrent.futures import Future
 from typing import Callable, Dict, List, Optional, Sequence
 
+import torch
+
 from ..pdf import reader
 from .batcher import DynamicBatcher, page_cost_bytes, shape_key
 from .document import DocumentPipeline
@@ -176,6 +178,12 @@ class EngineService:
         s["mean_batch_pages"] = round(self.pages_in_batches / self.batches, 2) if self.batches else 0.0
         with self._mu:
             s["documents_in_flight"] = len(self._jobs)
+        # cumulative seconds per pipeline stage (host decode wait, detector submit / wait, recogniser, finish) and the
+        # HBM this process holds: exported per worker through GET /metrics
+        s["stage_seconds"] = {**self.pipeline.timer.summary(), **self.engine.timer.summary()}
+        if self.engine.on_gpu:
+            s["hbm_allocated_bytes"] = int(torch.cuda.memory_allocated(self.engine.device))
+            s["hbm_reserved_bytes"] = int(torch.cuda.memory_reserved(self.engine.device))
         return s
 
     def close(self, timeout: float = 10.0) -> None:

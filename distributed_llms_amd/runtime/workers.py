@@ -245,6 +245,7 @@ class WorkerPool:
         self.restarts = 0
         self.pages_done = 0
         self.batch_stats: Dict[str, float] = {}
+        self.worker_stats: Dict[int, Dict[str, object]] = {}     # last EngineService.stats() of every worker
         self._job_seq = 0
 
     # -- lifecycle
@@ -402,6 +403,7 @@ class WorkerPool:
                     for i, pr in msg[4]:
                         job.pages[i] = pr
                     self.pages_done += len(msg[4])
+                    self.worker_stats[wid] = dict(msg[5] or {})
                     for k, v in (msg[5] or {}).items():
                         if isinstance(v, (int, float)):
                             self.batch_stats[k] = v
@@ -476,4 +478,5 @@ class WorkerPool:
             return {"workers": self.num_workers, "alive": sum(p is not None and p.is_alive() for p in self.procs),
                     "ready": sum(self.ready), "disabled": sum(self.disabled),
                     "restarts": self.restarts, "jobs_in_flight": len(self.jobs), "pages_done": self.pages_done,
-                    "queue_depth": [self._load(w) for w in range(self.num_workers)], "batcher": dict(self.batch_stats)}
+                    "queue_depth": [self._load(w) for w in range(self.num_workers)], "batcher": dict(self.batch_stats),
+                    "worker_stats": {w: dict(v) for w, v in self.worker_stats.items()}}

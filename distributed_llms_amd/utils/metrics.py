@@ -15,10 +15,21 @@ QUEUE_DEPTH = Gauge("ocr_worker_queue_pages", "Pages queued per GPU worker", ["w
 WORKERS_ALIVE = Gauge("ocr_workers_alive", "GPU worker processes alive", registry=REGISTRY)
 WORKER_RESTARTS = Gauge("ocr_worker_restarts", "GPU worker respawns since start", registry=REGISTRY)
 BATCH_FILL = Gauge("ocr_batch_fill_ratio", "Full batches / all batches emitted by the dynamic batcher", registry=REGISTRY)
-GPU_MEM = Gauge("ocr_gpu_memory_bytes", "HBM in use per GPU", ["gpu"], registry=REGISTRY)
+GPU_MEM = Gauge("ocr_gpu_memory_bytes", "HBM held by the engine process of each GPU worker", ["gpu", "kind"], registry=REGISTRY)
+ENGINE_STAGE = Gauge("ocr_engine_stage_seconds_total", "Cumulative wall-clock seconds the engine loop spent per stage",
+                     ["worker", "stage"], registry=REGISTRY)
 STAGE_SECONDS = Histogram(
     "ocr_stage_seconds", "Latency per pipeline stage", ["stage"], registry=REGISTRY,
     buckets=(0.005, 0.01, 0.025, 0.05, 0.1, 0.25, 0.5, 1, 2.5, 5, 10, 30, 60, 120, 300, 600))
+
+
+def _export_engine_stats(worker: str, st: dict) -> None:
+    for stage, sec in (st.get("stage_seconds") or {}).items():
+        ENGINE_STAGE.labels(worker, stage).set(sec)
+    for kind in ("allocated", "reserved"):
+        v = st.get(f"hbm_{kind}_bytes")
+        if v is not None:
+            GPU_MEM.labels(worker, kind).set(v)
 
 
 def refresh_from_extractor(extractor) -> None:
@@ -32,16 +43,13 @@ def refresh_from_extractor(extractor) -> None:
         WORKER_RESTARTS.set(d.get("restarts", 0))
         for i, q in enumerate(d.get("queue_depth", [])):
             QUEUE_DEPTH.labels(str(i)).set(q)
-        b = d.get("batcher") or {}
-        if b.get("batches"):
-            BATCH_FILL.set(b.get("full_batches", 0) / b["batches"])
-    try:
-        import torch
-
-        if torch.cuda.is_available() and d.get("backend") == "inline":
-            GPU_MEM.labels("0").set(torch.cuda.memory_allocated(0))
-    except Exception:
-        pass
+        for w, st in (d.get("worker_stats") or {}).items():
+            _export_engine_stats(str(w), st)
+    else:
+        _export_engine_stats("0", d)      # in-process engine
+    b = d.get("batcher") or d
+    if b.get("batches"):
+        BATCH_FILL.set(b.get("full_batches", 0) / b["batches"])
 
 
 def render() -> bytes:

@@ -294,3 +294,35 @@ def test_upload_cap_holds_without_content_length(ctx, monkeypatch):
         r = c.post("/extract", content=gen(), headers={"content-type": ctype})
         assert r.status_code == 413
         assert c.get("/check-status/big").status_code == 404
+
+
+def test_metrics_export_engine_stage_timers_and_worker_memory(ctx):
+    """GET /metrics carries the engine loop's per-stage seconds (in-process engine) and, for a GPU pool, the last
+    stage timers and HBM figures every worker reported."""
+    from distributed_llms_amd.utils import metrics
+
+    settings, status, results = ctx
+    app = create_app(settings, status, results, _cpu_extractor())
+    pg, _ = synth.render_page(5, size=(248, 350), font_px=10, margin=16)
+    pdf = synth.make_scanned_pdf([pg], codec="flate", dpi=30)
+    with TestClient(app) as c:
+        assert _post(c, pdf, "scan-m").json() == {"status": "ok"}
+        _wait(c, "scan-m")
+        text = c.get("/metrics").text
+    assert 'ocr_engine_stage_seconds_total{stage="wait_det",worker="0"}' in text
+    assert 'ocr_engine_stage_seconds_total{stage="submit_det",worker="0"}' in text
+
+    class PoolLike:
+        def describe(self):
+            return {"backend": "gpu-pool", "alive": 2, "restarts": 1, "queue_depth": [3, 0],
+                    "batcher": {"batches": 4, "full_batches": 3},
+                    "worker_stats": {0: {"stage_seconds": {"wait_det": 1.5}, "hbm_allocated_bytes": 7 << 30,
+                                         "hbm_reserved_bytes": 9 << 30},
+                                     1: {"stage_seconds": {"wait_det": 0.25}, "hbm_allocated_bytes": 6 << 30}}}
+
+    metrics.refresh_from_extractor(PoolLike())
+    text = metrics.render().decode()
+    assert 'ocr_engine_stage_seconds_total{stage="wait_det",worker="1"} 0.25' in text
+    assert 'ocr_gpu_memory_bytes{gpu="0",kind="reserved"} 9.663676416e+09' in text
+    assert 'ocr_gpu_memory_bytes{gpu="1",kind="allocated"}' in text
+    assert "ocr_batch_fill_ratio 0.75" in text

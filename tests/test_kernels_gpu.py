@@ -22,6 +22,10 @@ def _close(a, b, rtol=2e-2, atol=2e-2):
     tol = atol + rtol * b.abs()
     bad = (err > tol).float().mean().item()
     assert bad < 1e-3, f"mismatch fraction {bad:.4f}, max err {err.max().item():.4f}"
+    # bf16 rounding may push a few elements past the tolerance, but never far past it: a tile edge that reads or
+    # writes the wrong element is off by the magnitude of the data, not by a rounding step
+    worst = (err / tol).max().item()
+    assert worst < 8.0, f"an element is off by {worst:.1f}x the tolerance (max err {err.max().item():.4f})"
 
 
 CONV_CASES = [
