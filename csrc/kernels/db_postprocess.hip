@@ -12,9 +12,11 @@
 //                   in-register first (text blobs are wide, so a wave64 almost
 //                   always sits inside one component) -> one atomic set per
 //                   wave instead of 64 contended ones.
-//   4. box_finalize score filter, closed-form rectangle "unclip"
+//   4. box_finalize score filter, orientation from the component's second moments (a skewed scan gives slanted
+//                   text lines: the box becomes the minimum-area rectangle around the blob, reported as an upright
+//                   rectangle plus the angle to turn it by about its centre), closed-form rectangle "unclip"
 //                   (d = area * ratio / perimeter), rescale to page pixels.
-// Output is a small [B, max_boxes, 6] float table + per-page counts.
+// Output is a small [B, max_boxes, 8] float table + per-page counts.
 #include "common.h"
 
 #define MAXC_DEFAULT 4096
@@ -109,7 +111,9 @@ __global__ void ccl_assign_kernel(int* __restrict__ parent_all, int* __restrict_
   }
 }
 
-// stats layout per component: [xmin, ymin, xmax, ymax, count, sum(prob) as float bits]
+// stats layout per component, STAT_STRIDE int32 words: [xmin, ymin, xmax, ymax, count, sum(prob) as float bits,
+// then five 64-bit sums over the component's pixels: x, y, x*x, y*y, x*y] (exact integers: box angles do not depend
+// on the order the atomics land in).
 //
 // Contention control, three levels deep (a text blob is wide and many rows tall, so naive per-pixel
 // atomics all hit the same six words):
@@ -118,6 +122,18 @@ __global__ void ccl_assign_kernel(int* __restrict__ parent_all, int* __restrict_
 //   3. one global atomic set per (block, component) is issued at the end.
 #define STAT_SLOTS 64
 #define STAT_ROWS 16
+#define STAT_STRIDE 16
+
+// n pixels of one component with block-relative sums (x' = x - bx0, y' = y - by0) -> absolute sums, added to global
+__device__ __forceinline__ void moments_global_add(int* __restrict__ s, long long n, long long sx, long long sy, long long sxx,
+                                                   long long syy, long long sxy, long long bx0, long long by0) {
+  unsigned long long* m = reinterpret_cast<unsigned long long*>(s + 6);
+  atomicAdd(&m[0], (unsigned long long)(sx + n * bx0));
+  atomicAdd(&m[1], (unsigned long long)(sy + n * by0));
+  atomicAdd(&m[2], (unsigned long long)(sxx + 2 * bx0 * sx + n * bx0 * bx0));
+  atomicAdd(&m[3], (unsigned long long)(syy + 2 * by0 * sy + n * by0 * by0));
+  atomicAdd(&m[4], (unsigned long long)(sxy + bx0 * sy + by0 * sx + n * bx0 * by0));
+}
 
 __device__ __forceinline__ void stats_global_add(int* __restrict__ s, int xmin, int ymin, int xmax, int ymax, int cnt,
                                                  float ps) {
@@ -135,10 +151,12 @@ __global__ __launch_bounds__(256) void ccl_stats_kernel(const bf16_t* __restrict
   __shared__ int t_cid[STAT_SLOTS];
   __shared__ int t_xmin[STAT_SLOTS], t_ymin[STAT_SLOTS], t_xmax[STAT_SLOTS], t_ymax[STAT_SLOTS], t_cnt[STAT_SLOTS];
   __shared__ float t_ps[STAT_SLOTS];
+  __shared__ int t_sx[STAT_SLOTS], t_sy[STAT_SLOTS], t_sxx[STAT_SLOTS], t_syy[STAT_SLOTS], t_sxy[STAT_SLOTS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < STAT_SLOTS) {
     t_cid[tid] = -1; t_xmin[tid] = 0x7fffffff; t_ymin[tid] = 0x7fffffff; t_xmax[tid] = -1; t_ymax[tid] = -1;
     t_cnt[tid] = 0; t_ps[tid] = 0.f;
+    t_sx[tid] = 0; t_sy[tid] = 0; t_sxx[tid] = 0; t_syy[tid] = 0; t_sxy[tid] = 0;
   }
   __syncthreads();
   const int x = blockIdx.x * 64 + lane;
@@ -171,12 +189,15 @@ __global__ __launch_bounds__(256) void ccl_stats_kernel(const bf16_t* __restrict
       int vxmin = same ? x : 0x7fffffff, vxmax = same ? x : -1;
       int vcnt = same ? 1 : 0;
       float vps = same ? pv : 0.f;
+      int vsx = same ? lane : 0, vsxx = same ? lane * lane : 0;        // x relative to the block's first column
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
         vxmin = min(vxmin, __shfl_xor(vxmin, o, 64));
         vxmax = max(vxmax, __shfl_xor(vxmax, o, 64));
         vcnt += __shfl_xor(vcnt, o, 64);
         vps += __shfl_xor(vps, o, 64);
+        vsx += __shfl_xor(vsx, o, 64);
+        vsxx += __shfl_xor(vsxx, o, 64);
       }
       if (lane == leader) {
         // insert / merge into the block's LDS table (open addressing, linear probing)
@@ -191,20 +212,33 @@ __global__ __launch_bounds__(256) void ccl_stats_kernel(const bf16_t* __restrict
             atomicMax(&t_ymax[slot], y);
             atomicAdd(&t_cnt[slot], vcnt);
             atomicAdd(&t_ps[slot], vps);
+            const int yr = y - blockIdx.y * STAT_ROWS;                   // a wave covers one row: y is uniform
+            atomicAdd(&t_sx[slot], vsx);
+            atomicAdd(&t_sxx[slot], vsxx);
+            atomicAdd(&t_sy[slot], vcnt * yr);
+            atomicAdd(&t_syy[slot], vcnt * yr * yr);
+            atomicAdd(&t_sxy[slot], vsx * yr);
             done = true;
           }
           slot = (slot + 1) & (STAT_SLOTS - 1);
         }
         // more than STAT_SLOTS distinct components inside one 64 x 16 block (salt-and-pepper masks): go direct
-        if (!done) stats_global_add(stats + ((long long)b * maxc + lc) * 6, vxmin, y, vxmax, y, vcnt, vps);
+        if (!done) {
+          int* sg = stats + ((long long)b * maxc + lc) * STAT_STRIDE;
+          stats_global_add(sg, vxmin, y, vxmax, y, vcnt, vps);
+          moments_global_add(sg, vcnt, vsx, 0, vsxx, 0, 0, (long long)blockIdx.x * 64, y);
+        }
       }
       todo &= ~grp;
     }
   }
   __syncthreads();
-  if (tid < STAT_SLOTS && t_cid[tid] >= 0)
-    stats_global_add(stats + ((long long)b * maxc + t_cid[tid]) * 6, t_xmin[tid], t_ymin[tid], t_xmax[tid], t_ymax[tid],
-                     t_cnt[tid], t_ps[tid]);
+  if (tid < STAT_SLOTS && t_cid[tid] >= 0) {
+    int* sg = stats + ((long long)b * maxc + t_cid[tid]) * STAT_STRIDE;
+    stats_global_add(sg, t_xmin[tid], t_ymin[tid], t_xmax[tid], t_ymax[tid], t_cnt[tid], t_ps[tid]);
+    moments_global_add(sg, t_cnt[tid], t_sx[tid], t_sy[tid], t_sxx[tid], t_syy[tid], t_sxy[tid],
+                       (long long)blockIdx.x * 64, (long long)blockIdx.y * STAT_ROWS);
+  }
 }
 
 __global__ void stats_init_kernel(int* __restrict__ stats, int* __restrict__ ncomp, int* __restrict__ nbox, int n,
@@ -212,22 +246,28 @@ __global__ void stats_init_kernel(int* __restrict__ stats, int* __restrict__ nco
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B) { ncomp[i] = 0; nbox[i] = 0; }
   if (i >= n) return;
-  int* s = stats + (long long)i * 6;
+  int* s = stats + (long long)i * STAT_STRIDE;
   s[0] = 0x7fffffff; s[1] = 0x7fffffff; s[2] = -1; s[3] = -1; s[4] = 0; s[5] = 0;
+#pragma unroll
+  for (int k = 6; k < STAT_STRIDE; ++k) s[k] = 0;
 }
 
 // page_scale: [B, 2] float (sx, sy): multiply det-map coords to get page pixel coords.
 // valid: [B, 2] int (valid_w, valid_h) of the det map (content area, rest is bucket padding)
-// boxes: [B, max_boxes, 6] float: x0, y0, x1, y1 (page pixels), score, pixel count
+// boxes: [B, max_boxes, 8] float: x0, y0, x1, y1 (page pixels), score, pixel count, angle, 0.  With angle != 0 the
+// text line is the rectangle x0..y1 turned by `angle` radians about its centre (positive = the line runs down to the
+// right in image coordinates).
+// max_angle: largest |angle| reported (radians); wider components whose principal axis is tilted less than this get
+// an oriented box, everything else (and max_angle = 0) the upright bounding box.
 __global__ void box_finalize_kernel(const int* __restrict__ stats, const int* __restrict__ ncomp,
                                     const float* __restrict__ page_scale, const int* __restrict__ valid,
                                     float* __restrict__ boxes, int* __restrict__ nbox, int maxc, int max_boxes,
-                                    float box_thresh, float unclip_ratio, int min_size, int H, int W) {
+                                    float box_thresh, float unclip_ratio, int min_size, float max_angle, int H, int W) {
   int cidx = blockIdx.x * blockDim.x + threadIdx.x;
   int b = blockIdx.y;
   int nc = min(ncomp[b], maxc);
   if (cidx >= nc) return;
-  const int* s = stats + ((long long)b * maxc + cidx) * 6;
+  const int* s = stats + ((long long)b * maxc + cidx) * STAT_STRIDE;
   int cnt = s[4];
   if (cnt <= 0) return;
   float score = __builtin_bit_cast(float, s[5]) / (float)cnt;
@@ -235,24 +275,65 @@ __global__ void box_finalize_kernel(const int* __restrict__ stats, const int* __
   float w = x1 - x0, h = y1 - y0;
   if (fminf(w, h) < (float)min_size) return;
   if (score < box_thresh) return;
-  float d = (w * h) * unclip_ratio / (2.f * (w + h));
-  int vw = valid ? valid[b * 2] : W, vh = valid ? valid[b * 2 + 1] : H;
-  x0 = fmaxf(x0 - d, 0.f); y0 = fmaxf(y0 - d, 0.f);
-  x1 = fminf(x1 + d, (float)vw); y1 = fminf(y1 + d, (float)vh);
-  if (x1 - x0 < (float)(min_size + 2) || y1 - y0 < (float)(min_size + 2)) return;
-  float sx = page_scale ? page_scale[b * 2] : 1.f, sy = page_scale ? page_scale[b * 2 + 1] : 1.f;
+  const float sx = page_scale ? page_scale[b * 2] : 1.f, sy = page_scale ? page_scale[b * 2 + 1] : 1.f;
+  // orientation: principal axis of the pixel distribution
+  float angle = 0.f;
+  double l_major = 0.0, l_minor = 0.0, mx = 0.0, my = 0.0;
+  if (max_angle > 0.f && w >= 3.f * h) {
+    const long long* m = reinterpret_cast<const long long*>(s + 6);
+    const double n = (double)cnt;
+    mx = (double)m[0] / n;
+    my = (double)m[1] / n;
+    const double u20 = (double)m[2] / n - mx * mx, u02 = (double)m[3] / n - my * my, u11 = (double)m[4] / n - mx * my;
+    const double th = 0.5 * atan2(2.0 * u11, u20 - u02);
+    const double r = sqrt(0.25 * (u20 - u02) * (u20 - u02) + u11 * u11);
+    l_major = 0.5 * (u20 + u02) + r;
+    l_minor = fmax(0.5 * (u20 + u02) - r, 0.0);
+    if (fabs(th) <= (double)max_angle && fabs(th) >= 0.004 && l_major >= 16.0 * (l_minor + 1.0 / 12.0)) angle = (float)th;
+  }
+  if (angle == 0.f) {
+    float d = (w * h) * unclip_ratio / (2.f * (w + h));
+    int vw = valid ? valid[b * 2] : W, vh = valid ? valid[b * 2 + 1] : H;
+    x0 = fmaxf(x0 - d, 0.f); y0 = fmaxf(y0 - d, 0.f);
+    x1 = fminf(x1 + d, (float)vw); y1 = fminf(y1 + d, (float)vh);
+    if (x1 - x0 < (float)(min_size + 2) || y1 - y0 < (float)(min_size + 2)) return;
+    int slot = atomicAdd(&nbox[b], 1);
+    if (slot >= max_boxes) return;
+    float* o = boxes + ((long long)b * max_boxes + slot) * 8;
+    o[0] = x0 * sx; o[1] = y0 * sy; o[2] = x1 * sx; o[3] = y1 * sy; o[4] = score; o[5] = (float)cnt; o[6] = 0.f; o[7] = 0.f;
+    return;
+  }
+  // A rectangle L x T turned by `angle` has the upright bounding box w = L c + T s, h = L s + T c (c = cos, s = |sin|):
+  // solve for L and T (exact for a filled rectangle, and driven by the outermost pixels, so ragged line ends do not
+  // shorten the box), bounded below by the extents the second moments imply (variance of a uniform bar = length^2 / 12).
+  const float c = cosf(angle), sg = sinf(angle), sa = fabsf(sg);
+  const float c2 = c * c - sa * sa;
+  float L = (w * c - h * sa) / c2, T = (h * c - w * sa) / c2;
+  L = fminf(fmaxf(L, 0.8f * sqrtf(12.f * (float)l_major)), sqrtf(w * w + h * h));
+  T = fminf(fmaxf(T, fmaxf(1.f, 0.8f * sqrtf(12.f * (float)l_minor + 1.f))), h);
+  if (T < (float)min_size) return;
+  const float d = (L * T) * unclip_ratio / (2.f * (L + T));
+  L += 2.f * d;
+  T += 2.f * d;
+  if (L < (float)(min_size + 2) || T < (float)(min_size + 2)) return;
+  // to page pixels (sx and sy may differ slightly): directions scale component-wise
+  const float ux = c * sx, uy = sg * sy, vx = -sg * sx, vy = c * sy;
+  const float Lp = L * sqrtf(ux * ux + uy * uy), Tp = T * sqrtf(vx * vx + vy * vy);
+  const float ap = atan2f(uy, ux);
+  const float cxp = ((float)mx + 0.5f) * sx, cyp = ((float)my + 0.5f) * sy;
   int slot = atomicAdd(&nbox[b], 1);
   if (slot >= max_boxes) return;
-  float* o = boxes + ((long long)b * max_boxes + slot) * 6;
-  o[0] = x0 * sx; o[1] = y0 * sy; o[2] = x1 * sx; o[3] = y1 * sy; o[4] = score; o[5] = (float)cnt;
+  float* o = boxes + ((long long)b * max_boxes + slot) * 8;
+  o[0] = cxp - 0.5f * Lp; o[1] = cyp - 0.5f * Tp; o[2] = cxp + 0.5f * Lp; o[3] = cyp + 0.5f * Tp;
+  o[4] = score; o[5] = (float)cnt; o[6] = ap; o[7] = 0.f;
 }
 
 // mask: [B,H,W] u8, prob: [B,H,W] bf16.  Workspaces: parent, comp_id: [B,H,W] int32;
-// stats: [B,maxc,6] int32; ncomp, nbox: [B] int32.
+// stats: [B,maxc,16] int32 (8-byte aligned); ncomp, nbox: [B] int32.  boxes: [B,max_boxes,8] float.
 extern "C" int dlamd_db_postprocess(const void* mask, const void* prob, void* parent, void* comp_id, void* stats,
                                     void* ncomp, void* nbox, const float* page_scale, const int* valid, float* boxes,
                                     int B, int H, int W, int maxc, int max_boxes, float box_thresh,
-                                    float unclip_ratio, int min_size, hipStream_t stream) {
+                                    float unclip_ratio, int min_size, float max_angle, hipStream_t stream) {
   if (B <= 0) return 0;
   if ((long long)H * W > 0x7fffffffLL || B > 65535) return -1;
   const int hw = H * W;
@@ -272,6 +353,6 @@ extern "C" int dlamd_db_postprocess(const void* mask, const void* prob, void* pa
                      (const int*)comp_id, (int*)stats, H, W, maxc);
   hipLaunchKernelGGL(box_finalize_kernel, dim3((maxc + 255) / 256, B), dim3(256), 0, stream, (const int*)stats,
                      (const int*)ncomp, page_scale, valid, boxes, (int*)nbox, maxc, max_boxes, box_thresh,
-                     unclip_ratio, min_size, H, W);
+                     unclip_ratio, min_size, max_angle, H, W);
   return DLAMD_CHECK_LAUNCH();
 }

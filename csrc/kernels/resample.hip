@@ -8,7 +8,9 @@
 // bf16 and write NHWC with the channel dimension padded to 8 so that the first
 // convolution sees 16-byte pixels.  Pixels outside the valid output size are
 // written as zeros (bucket padding).  Optional 90-degree rotation for tall
-// (vertical) boxes.
+// (vertical) boxes, and an arbitrary angle about the region's centre for the
+// slanted text lines of a skewed scan (affine crop: up to 4 x 4 bilinear taps
+// per output pixel stand in for the box filter).
 //
 // Memory-bound: each thread produces one output pixel = one 16-byte store;
 // neighbouring lanes read neighbouring source spans.
@@ -21,7 +23,7 @@ struct ResampleItem {
   float x0, y0, x1, y1; // source region (pixels, half-open, may be fractional)
   int out_h, out_w;     // valid output size (<= Hd, Wd)
   int pitch;            // source row pitch in bytes (0: Ws * C)
-  int pad1;
+  float angle;          // radians; != 0: the region is the rectangle x0..y1 turned by this angle about its centre
 };
 static_assert(sizeof(ResampleItem) == 56, "ResampleItem layout is part of the Python ABI");
 
@@ -60,7 +62,32 @@ __global__ __launch_bounds__(256) void resample_kernel(const ResampleItem* __res
   const int C = it.C;
   const uint8_t* src = it.src;
   const long long pitch = it.pitch > 0 ? it.pitch : (long long)it.Ws * C;
-  if (su > 1.f || sv > 1.f) {
+  if (it.angle != 0.f) {
+    // affine crop: sample positions are laid out in the rectangle's own frame and turned into the source frame
+    const float ca = cosf(it.angle), sa = sinf(it.angle);
+    const float cx = 0.5f * (it.x0 + it.x1), cy = 0.5f * (it.y0 + it.y1);
+    const int nx = min(4, max(1, (int)ceilf(su))), ny = min(4, max(1, (int)ceilf(sv)));
+    for (int j = 0; j < ny; ++j) {
+      const float ly = (v + (j + 0.5f) / ny) * sv - 0.5f * rh;
+      for (int i = 0; i < nx; ++i) {
+        const float lx = (u + (i + 0.5f) / nx) * su - 0.5f * rw;
+        float px = cx + lx * ca - ly * sa - 0.5f, py = cy + lx * sa + ly * ca - 0.5f;
+        px = fminf(fmaxf(px, 0.f), (float)(it.Ws - 1));
+        py = fminf(fmaxf(py, 0.f), (float)(it.Hs - 1));
+        const int xa = (int)floorf(px), ya = (int)floorf(py);
+        const int xb = min(xa + 1, it.Ws - 1), yb = min(ya + 1, it.Hs - 1);
+        const float fx = px - xa, fy = py - ya;
+        const uint8_t* r0 = src + (long long)ya * pitch;
+        const uint8_t* r1 = src + (long long)yb * pitch;
+        for (int ch = 0; ch < C; ++ch) {
+          const float a = r0[xa * C + ch], b2 = r0[xb * C + ch], c2 = r1[xa * C + ch], d = r1[xb * C + ch];
+          acc[ch] += (a * (1.f - fx) + b2 * fx) * (1.f - fy) + (c2 * (1.f - fx) + d * fx) * fy;
+        }
+      }
+    }
+    const float inv = 1.f / (float)(nx * ny);
+    acc[0] *= inv; acc[1] *= inv; acc[2] *= inv;
+  } else if (su > 1.f || sv > 1.f) {
     // fractional box filter over [lo, hi)
     float xlo = it.x0 + u * su, xhi = xlo + su;
     float ylo = it.y0 + v * sv, yhi = ylo + sv;

@@ -11,7 +11,12 @@ the MI355X inference path:
   smooth conv writes its 64 channels, replicated fxf, straight into its channel
   slice of the 1/4-scale concat buffer;
 * both 2x2/s2 transposed convs are GEMMs with a pixel-shuffle store; the last one
-  applies sigmoid and emits the probability map and the >thr bitmask together.
+  applies sigmoid and emits the probability map and the >thr bitmask together;
+* a second, block-level head on the same 1/4-scale features (one 3x3 conv) marks
+  figure regions: the engine turns it into figure boxes with the same connected-
+  component kernels, keeps figures out of the text flow and hands their crops to
+  the image writer.  The reference gets its block layout from a separate YOLO
+  layout model (services/ocr_service/download_models_hf.py:38).
 
 In the reference the detector is the PaddleOCR-torch DB model downloaded by
 services/ocr_service/download_models_hf.py:41 and executed on CPU inside
@@ -56,6 +61,7 @@ class DBNet(nn.Module):
         self.head1 = ConvBNAct(inner, q, 3, 1, act="relu")
         self.head2 = Deconv2x2(q, q, act="relu", bn=True)
         self.head3 = Deconv2x2(q, 1, act="sigmoid", bn=False)
+        self.fig_head = ConvBNAct(q, 8, 3, 1, act="none", bn=False)     # channel 0: figure logit at 1/4 scale
         self.fuse_head_tail = True      # device inference: ops/conv.db_head_fused when q == 64
         self._head_tail = None
         self.inner, self.q = inner, q
@@ -64,10 +70,16 @@ class DBNet(nn.Module):
         with torch.no_grad():
             self.head3.deconv.weight.mul_(1e-2)
             self.head3.deconv.bias.fill_(-2.2)
+            self.fig_head.conv.weight.mul_(1e-2)
+            self.fig_head.conv.bias.fill_(-3.0)
 
     # ------------------------------------------------------------------ training path (NCHW)
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: [B,3,H,W] normalised -> probability map [B,H,W] (H, W multiples of 32)."""
+        return self.forward_all(x)[0]
+
+    def forward_all(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """-> (text probability [B,H,W], figure logit [B,H/4,W/4])."""
         y = self.stem3(self.stem2(self.stem1(x)))
         feats = []
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
@@ -84,12 +96,14 @@ class DBNet(nn.Module):
         p3 = F.interpolate(self.p3(o3), scale_factor=2, mode="nearest")
         p2 = self.p2(o2)
         fuse = torch.cat([p5, p4, p3, p2], dim=1)
-        return self.head3(self.head2(self.head1(fuse)))[:, 0]
+        h = self.head1(fuse)
+        return self.head3(self.head2(h))[:, 0], self.fig_head(h)[:, 0]
 
     # ------------------------------------------------------------------ inference path (NHWC bf16)
     @torch.no_grad()
-    def infer(self, x: torch.Tensor, concat_buf: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-        """x: [B,H,W,8] bf16 -> (prob [B,H,W] bf16, mask [B,H,W] u8)."""
+    def infer(self, x: torch.Tensor, concat_buf: Optional[torch.Tensor] = None, with_figures: bool = False):
+        """x: [B,H,W,8] bf16 -> (prob [B,H,W] bf16, mask [B,H,W] u8); with_figures adds the block head's output
+        [B,H/4,W/4,8] bf16 (channel 0 = figure logit)."""
         B, H, W, _ = x.shape
         assert H % 32 == 0 and W % 32 == 0, "detector input must be a multiple of 32"
         y = self.stem3.infer(self.stem2.infer(self.stem1.infer(x)))
@@ -111,6 +125,13 @@ class DBNet(nn.Module):
         self.p3.infer(o3, out=concat_buf, out_coff=2 * q, out_mode=C.OUT_REPLICATE, out_f=2)
         self.p2.infer(o2, out=concat_buf, out_coff=3 * q)
         h = self.head1.infer(concat_buf)
+        fig = self.fig_head.infer(h) if with_figures else None
+        if with_figures:
+            return self._infer_tail(h) + (fig,)
+        return self._infer_tail(h)
+
+    def _infer_tail(self, h: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        q = self.q
         if self.fuse_head_tail and h.is_cuda and q == 64 and h.shape[2] % 2 == 0:
             # both deconvs + sigmoid + threshold in one kernel: the half-resolution 64-channel map never hits HBM
             if self._head_tail is None:

@@ -14,6 +14,7 @@ Thresholds default to the published DBNet values (binarise 0.3, box score
 """
 from __future__ import annotations
 
+import math
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
@@ -31,35 +32,69 @@ class DBPostConfig:
     min_size: int = 3
     max_components: int = 4096
     max_boxes: int = 1024
+    max_angle_deg: float = 20.0     # wide components tilted less than this get an oriented box (0: upright boxes only)
 
 
 def _finalize(stats, scale, valid, cfg: DBPostConfig, H: int, W: int) -> np.ndarray:
-    """Shared arithmetic of box_finalize_kernel for one page (numpy, float32)."""
+    """Shared arithmetic of box_finalize_kernel for one page (numpy).  ``stats`` rows: xmin, ymin, xmax, ymax, count,
+    sum(prob), sum x, sum y, sum x^2, sum y^2, sum xy."""
     out = []
-    sx, sy = (float(scale[0]), float(scale[1])) if scale is not None else (1.0, 1.0)
+    sx, sy = (np.float32(scale[0]), np.float32(scale[1])) if scale is not None else (np.float32(1), np.float32(1))
     vw, vh = (int(valid[0]), int(valid[1])) if valid is not None else (W, H)
-    for (xmin, ymin, xmax, ymax, cnt, psum) in stats:
+    f32 = np.float32
+    max_angle = math.radians(cfg.max_angle_deg)
+    for (xmin, ymin, xmax, ymax, cnt, psum, SX, SY, SXX, SYY, SXY) in stats:
         if cnt <= 0:
             continue
-        score = np.float32(psum) / np.float32(cnt)
-        x0, y0, x1, y1 = np.float32(xmin), np.float32(ymin), np.float32(xmax + 1), np.float32(ymax + 1)
+        score = f32(psum) / f32(cnt)
+        x0, y0, x1, y1 = f32(xmin), f32(ymin), f32(xmax + 1), f32(ymax + 1)
         w, h = x1 - x0, y1 - y0
-        if min(w, h) < cfg.min_size or score < np.float32(cfg.box_thresh):
+        if min(w, h) < cfg.min_size or score < f32(cfg.box_thresh):
             continue
-        d = (w * h) * np.float32(cfg.unclip_ratio) / (np.float32(2.0) * (w + h))
-        x0, y0 = max(x0 - d, np.float32(0)), max(y0 - d, np.float32(0))
-        x1, y1 = min(x1 + d, np.float32(vw)), min(y1 + d, np.float32(vh))
-        if x1 - x0 < cfg.min_size + 2 or y1 - y0 < cfg.min_size + 2:
+        angle = 0.0
+        if max_angle > 0 and w >= 3 * h:
+            n = float(cnt)
+            mx, my = SX / n, SY / n
+            u20, u02, u11 = SXX / n - mx * mx, SYY / n - my * my, SXY / n - mx * my
+            th = 0.5 * math.atan2(2.0 * u11, u20 - u02)
+            r = math.sqrt(0.25 * (u20 - u02) ** 2 + u11 * u11)
+            l_major, l_minor = 0.5 * (u20 + u02) + r, max(0.5 * (u20 + u02) - r, 0.0)
+            if 0.004 <= abs(th) <= max_angle and l_major >= 16.0 * (l_minor + 1.0 / 12.0):
+                angle = float(f32(th))
+        if angle == 0.0:
+            d = (w * h) * f32(cfg.unclip_ratio) / (f32(2.0) * (w + h))
+            x0, y0 = max(x0 - d, f32(0)), max(y0 - d, f32(0))
+            x1, y1 = min(x1 + d, f32(vw)), min(y1 + d, f32(vh))
+            if x1 - x0 < cfg.min_size + 2 or y1 - y0 < cfg.min_size + 2:
+                continue
+            out.append([x0 * sx, y0 * sy, x1 * sx, y1 * sy, score, f32(cnt), f32(0), f32(0)])
             continue
-        out.append([x0 * sx, y0 * sy, x1 * sx, y1 * sy, score, np.float32(cnt)])
-    return np.asarray(out, dtype=np.float32).reshape(-1, 6)
+        c, sg = f32(math.cos(angle)), f32(math.sin(angle))
+        sa = abs(sg)
+        c2 = c * c - sa * sa
+        L, T = (w * c - h * sa) / c2, (h * c - w * sa) / c2
+        L = min(max(L, f32(0.8) * f32(math.sqrt(12.0 * l_major))), f32(math.hypot(w, h)))
+        T = min(max(T, max(f32(1), f32(0.8) * f32(math.sqrt(12.0 * l_minor + 1.0)))), h)
+        if T < cfg.min_size:
+            continue
+        d = (L * T) * f32(cfg.unclip_ratio) / (f32(2.0) * (L + T))
+        L, T = L + 2 * d, T + 2 * d
+        if L < cfg.min_size + 2 or T < cfg.min_size + 2:
+            continue
+        ux, uy, vx, vy = c * sx, sg * sy, -sg * sx, c * sy
+        Lp, Tp = L * f32(math.hypot(ux, uy)), T * f32(math.hypot(vx, vy))
+        ap = f32(math.atan2(uy, ux))
+        cxp, cyp = (f32(mx) + f32(0.5)) * sx, (f32(my) + f32(0.5)) * sy
+        out.append([cxp - f32(0.5) * Lp, cyp - f32(0.5) * Tp, cxp + f32(0.5) * Lp, cyp + f32(0.5) * Tp, score, f32(cnt), ap, f32(0)])
+    return np.asarray(out, dtype=np.float32).reshape(-1, 8)
 
 
 def db_postprocess_reference(
     prob: torch.Tensor, mask: torch.Tensor, cfg: DBPostConfig,
     page_scale: Optional[torch.Tensor] = None, valid: Optional[torch.Tensor] = None,
 ) -> List[np.ndarray]:
-    """prob [B,H,W] (any float), mask [B,H,W] u8 -> list of [n_i, 6] float32 box tables."""
+    """prob [B,H,W] (any float), mask [B,H,W] u8 -> list of [n_i, 8] float32 box tables (x0, y0, x1, y1, score, pixel
+    count, angle in radians, 0)."""
     from scipy import ndimage
 
     B, H, W = mask.shape
@@ -72,11 +107,15 @@ def db_postprocess_reference(
         stats = []
         if n > 0:
             objs = ndimage.find_objects(lab)
-            sums = ndimage.sum(pr[b], lab, index=np.arange(1, n + 1))
-            cnts = ndimage.sum(mk[b], lab, index=np.arange(1, n + 1))
+            idx = np.arange(1, n + 1)
+            sums = ndimage.sum(pr[b], lab, index=idx)
+            cnts = ndimage.sum(mk[b], lab, index=idx)
+            yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+            mom = [ndimage.sum(v, lab, index=idx) for v in (xx, yy, xx * xx, yy * yy, xx * yy)]
             for i, sl in enumerate(objs):
                 ys, xs = sl
-                stats.append((xs.start, ys.start, xs.stop - 1, ys.stop - 1, int(cnts[i]), float(sums[i])))
+                stats.append((xs.start, ys.start, xs.stop - 1, ys.stop - 1, int(cnts[i]), float(sums[i]),
+                              *(float(m[i]) for m in mom)))
         sc = None if page_scale is None else page_scale[b].cpu().numpy()
         vd = None if valid is None else valid[b].cpu().numpy()
         res.append(_finalize(stats, sc, vd, cfg, H, W))
@@ -90,17 +129,17 @@ class DBPostWorkspace:
         self.B, self.H, self.W, self.cfg = B, H, W, cfg
         self.parent = torch.empty((B, H, W), dtype=torch.int32, device=device)
         self.comp_id = torch.empty((B, H, W), dtype=torch.int32, device=device)
-        self.stats = torch.empty((B, cfg.max_components, 6), dtype=torch.int32, device=device)
+        self.stats = torch.empty((B, cfg.max_components, 16), dtype=torch.int32, device=device)
         self.ncomp = torch.empty((B,), dtype=torch.int32, device=device)
         self.nbox = torch.empty((B,), dtype=torch.int32, device=device)
-        self.boxes = torch.empty((B, cfg.max_boxes, 6), dtype=torch.float32, device=device)
+        self.boxes = torch.empty((B, cfg.max_boxes, 8), dtype=torch.float32, device=device)
 
 
 def db_postprocess_gpu(
     prob: torch.Tensor, mask: torch.Tensor, ws: DBPostWorkspace,
     page_scale: Optional[torch.Tensor] = None, valid: Optional[torch.Tensor] = None,
 ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Launch the device post-process.  Returns (boxes [B,max_boxes,6], nbox [B]) device tensors."""
+    """Launch the device post-process.  Returns (boxes [B,max_boxes,8], nbox [B]) device tensors."""
     B, H, W = mask.shape
     assert B <= ws.B and (H, W) == (ws.H, ws.W)
     assert prob.dtype == torch.bfloat16 and mask.dtype == torch.uint8
@@ -115,7 +154,7 @@ def db_postprocess_gpu(
         _loader.ptr(ws.stats), _loader.ptr(ws.ncomp), _loader.ptr(ws.nbox),
         _loader.ptr(page_scale), _loader.ptr(valid), _loader.ptr(ws.boxes),
         B, H, W, cfg.max_components, cfg.max_boxes, cfg.box_thresh, cfg.unclip_ratio, cfg.min_size,
-        _loader.stream_ptr(),
+        math.radians(cfg.max_angle_deg), _loader.stream_ptr(),
     )
     _loader.check(rc, "dlamd_db_postprocess")
     return ws.boxes, ws.nbox

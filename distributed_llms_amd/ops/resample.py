@@ -27,7 +27,7 @@ ITEM_DTYPE = np.dtype(
     [
         ("src", "<u8"), ("Hs", "<i4"), ("Ws", "<i4"), ("C", "<i4"), ("rot", "<i4"),
         ("x0", "<f4"), ("y0", "<f4"), ("x1", "<f4"), ("y1", "<f4"),
-        ("out_h", "<i4"), ("out_w", "<i4"), ("pitch", "<i4"), ("pad1", "<i4"),
+        ("out_h", "<i4"), ("out_w", "<i4"), ("pitch", "<i4"), ("angle", "<f4"),
     ],
     align=False,
 )
@@ -48,6 +48,7 @@ class Region:
     out_h: int
     out_w: int
     rot: int = 0
+    angle: float = 0.0      # radians: the region is ``box`` turned by this angle about its centre (slanted text line)
 
 
 def _axis_weights(lo0: float, scale: float, n_out: int, n_src: int, reverse: bool = False) -> torch.Tensor:
@@ -93,7 +94,9 @@ def resample_regions_reference(
         Hs, Ws, C = img.shape
         x0, y0, x1, y1 = r.box
         rw, rh = x1 - x0, y1 - y0
-        if r.rot == 0:
+        if r.angle != 0.0:
+            res = _affine_crop_reference(img, r)
+        elif r.rot == 0:
             su, sv = rw / r.out_w, rh / r.out_h
             # the kernel uses the box filter on both axes as soon as either axis shrinks
             if su > 1.0 or sv > 1.0:
@@ -120,6 +123,38 @@ def resample_regions_reference(
         res = (res / 255.0 - m) / s
         out[n, : r.out_h, : r.out_w, :3] = res.float()
     return out
+
+
+def _affine_crop_reference(img: torch.Tensor, r: Region) -> torch.Tensor:
+    """The kernel's affine path: up to 4 x 4 bilinear taps per output pixel, positions laid out in the rectangle's
+    frame and turned by ``angle`` about its centre.  img: [Hs, Ws, C] float64 -> [out_h, out_w, C]."""
+    Hs, Ws, C = img.shape
+    x0, y0, x1, y1 = (np.float32(v) for v in r.box)
+    rw, rh = x1 - x0, y1 - y0
+    if r.rot == 0:
+        su, sv = rw / np.float32(r.out_w), rh / np.float32(r.out_h)
+        u = np.arange(r.out_w, dtype=np.float32)[None, :].repeat(r.out_h, 0)
+        v = np.arange(r.out_h, dtype=np.float32)[:, None].repeat(r.out_w, 1)
+    else:
+        su, sv = rw / np.float32(r.out_h), rh / np.float32(r.out_w)
+        u = np.arange(r.out_h, dtype=np.float32)[:, None].repeat(r.out_w, 1)
+        v = (r.out_w - 1 - np.arange(r.out_w, dtype=np.float32))[None, :].repeat(r.out_h, 0)
+    ca, sa = np.float32(math.cos(r.angle)), np.float32(math.sin(r.angle))
+    cx, cy = np.float32(0.5) * (x0 + x1), np.float32(0.5) * (y0 + y1)
+    nx, ny = min(4, max(1, int(math.ceil(su)))), min(4, max(1, int(math.ceil(sv))))
+    a = img.numpy()
+    acc = np.zeros((r.out_h, r.out_w, C), dtype=np.float64)
+    for j in range(ny):
+        ly = (v + np.float32((j + 0.5) / ny)) * sv - np.float32(0.5) * rh
+        for i in range(nx):
+            lx = (u + np.float32((i + 0.5) / nx)) * su - np.float32(0.5) * rw
+            px = np.clip(cx + lx * ca - ly * sa - np.float32(0.5), 0, Ws - 1)
+            py = np.clip(cy + lx * sa + ly * ca - np.float32(0.5), 0, Hs - 1)
+            xa, ya = np.floor(px).astype(np.int64), np.floor(py).astype(np.int64)
+            xb, yb = np.minimum(xa + 1, Ws - 1), np.minimum(ya + 1, Hs - 1)
+            fx, fy = (px - xa)[..., None].astype(np.float64), (py - ya)[..., None].astype(np.float64)
+            acc += (a[ya, xa] * (1 - fx) + a[ya, xb] * fx) * (1 - fy) + (a[yb, xa] * (1 - fx) + a[yb, xb] * fx) * fy
+    return torch.from_numpy(acc / (nx * ny))
 
 
 def _axis_weights_box(lo0: float, scale: float, n_out: int, n_src: int, reverse: bool = False) -> torch.Tensor:
@@ -152,7 +187,7 @@ def pack_items(regions: Sequence[Region]) -> np.ndarray:
         # rows may be pitched (e.g. a [:H, :W] view of a JPEG plane padded to whole MCUs); pixels must be packed
         assert img.stride(1) == C and (img.dim() == 2 or img.stride(2) == 1), "pixels must be densely packed in a row"
         items[n] = (img.data_ptr(), Hs, Ws, C, r.rot, r.box[0], r.box[1], r.box[2], r.box[3], r.out_h, r.out_w,
-                    img.stride(0), 0)
+                    img.stride(0), r.angle)
     return items
 
 

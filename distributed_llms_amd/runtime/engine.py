@@ -78,6 +78,7 @@ class TextLine:
     text: str
     confidence: float
     block: int = 0               # text block (leaf region of the layout analysis); paragraphs never span blocks
+    angle: float = 0.0           # radians the line is turned about the centre of ``box`` (skewed scans), 0 = upright
 
 
 @dataclass
@@ -120,6 +121,12 @@ class EngineConfig:
     trocr_batch: int = 256            # crops per encoder / decoder pass of the transformer recognizer
     trocr_max_tokens: int = 64        # greedy decode length (the decoder runs a fixed number of steps)
     db: dbpost.DBPostConfig = field(default_factory=dbpost.DBPostConfig)
+    detect_figures: bool = True       # run the detector's block head and keep figure regions out of the text flow
+    # figure regions: components of the 1/4-scale block mask, no unclip, upright boxes
+    fig_db: dbpost.DBPostConfig = field(default_factory=lambda: dbpost.DBPostConfig(
+        bin_thresh=0.5, box_thresh=0.5, unclip_ratio=0.0, min_size=6, max_components=1024, max_boxes=32, max_angle_deg=0.0))
+    fig_min_side_px: int = 90         # smaller regions are not figures (page pixels)
+    max_figures_per_page: int = 8
 
 
 class StageTimer:
@@ -138,11 +145,29 @@ class StageTimer:
 
 
 class _DetBatch:
-    __slots__ = ("pages", "srcs", "boxes_host", "nbox_host", "event", "stream", "slot", "keep")
+    __slots__ = ("pages", "srcs", "boxes_host", "nbox_host", "fig_host", "nfig_host", "event", "stream", "slot", "keep")
 
 
 class _RecBatch:
-    __slots__ = ("det", "groups", "event", "results", "keep")
+    __slots__ = ("det", "groups", "event", "results", "keep", "fig_crops")
+
+
+def deskewed_boxes(b4: np.ndarray, angles: np.ndarray, page_hw: Tuple[int, int]) -> Tuple[np.ndarray, float]:
+    """Boxes of a skewed page in the frame of the upright page: every centre is turned back about the page centre by
+    the page's skew (median angle of its slanted lines), sizes stay.  Layout analysis cuts along whitespace that is
+    only straight in that frame.  Returns (boxes, skew in radians)."""
+    sl = angles[angles != 0.0]
+    if sl.size < 3 or sl.size < 0.3 * angles.size:
+        return b4, 0.0
+    a = float(np.median(sl))
+    if abs(a) < 0.004:
+        return b4, 0.0
+    H, W = page_hw
+    cx, cy = 0.5 * (b4[:, 0] + b4[:, 2]) - 0.5 * W, 0.5 * (b4[:, 1] + b4[:, 3]) - 0.5 * H
+    c, s_ = np.cos(-a), np.sin(-a)
+    rx, ry = cx * c - cy * s_ + 0.5 * W, cx * s_ + cy * c + 0.5 * H
+    hw, hh = 0.5 * (b4[:, 2] - b4[:, 0]), 0.5 * (b4[:, 3] - b4[:, 1])
+    return np.stack([rx - hw, ry - hh, rx + hw, ry + hh], 1).astype(np.float32), a
 
 
 class OcrEngine:
@@ -220,7 +245,14 @@ class OcrEngine:
                     srcs[i] = img
                 regions.append(rs.Region(img, (0.0, 0.0, float(img.shape[1]), float(img.shape[0])), oh, ow))
             x = self._resample(regions, Hd, Wd, rs.IMAGENET_MEAN, rs.IMAGENET_STD)
-            prob, mask = self.det.infer(x)
+            figs = cfg.detect_figures and hasattr(self.det, "fig_head")
+            fprob = fmask = None
+            if figs:
+                prob, mask, fig = self.det.infer(x, with_figures=True)
+                fl = fig[..., 0].float()
+                fprob, fmask = torch.sigmoid(fl).to(torch.bfloat16).contiguous(), (fl > 0).to(torch.uint8).contiguous()
+            else:
+                prob, mask = self.det.infer(x)
             scale = torch.tensor([[p.hw[1] / g[1], p.hw[0] / g[0]] for p, g in zip(pages, geo)],
                                  dtype=torch.float32)
             valid = torch.tensor([[g[1], g[0]] for g in geo], dtype=torch.int32)
@@ -237,12 +269,31 @@ class OcrEngine:
                 db.nbox_host = torch.empty((B,), dtype=torch.int32, pin_memory=True)
                 db.boxes_host.copy_(boxes[:B], non_blocking=True)
                 db.nbox_host.copy_(nbox[:B], non_blocking=True)
+                db.fig_host = db.nfig_host = None
+                keep_f = None
+                if figs:
+                    fkey = ("fig", slot, B, Hd // 4, Wd // 4)
+                    wf = self._ws.get(fkey)
+                    if wf is None:
+                        wf = dbpost.DBPostWorkspace(B, Hd // 4, Wd // 4, cfg.fig_db, self.device)
+                        self._ws[fkey] = wf
+                    fscale_d = (scale * 4.0).to(self.device, non_blocking=True)
+                    fvalid_d = ((valid + 3) // 4).to(self.device, non_blocking=True)
+                    fb, nf = dbpost.db_postprocess_gpu(fprob, fmask, wf, fscale_d, fvalid_d)
+                    db.fig_host = torch.empty(fb[:B].shape, dtype=fb.dtype, pin_memory=True)
+                    db.nfig_host = torch.empty((B,), dtype=torch.int32, pin_memory=True)
+                    db.fig_host.copy_(fb[:B], non_blocking=True)
+                    db.nfig_host.copy_(nf[:B], non_blocking=True)
+                    keep_f = (fprob, fmask, fscale_d, fvalid_d)
                 db.event = torch.cuda.Event()
                 db.event.record(st)
-                db.keep = (x, prob, mask, scale_d, valid_d)
+                db.keep = (x, prob, mask, scale_d, valid_d, keep_f)
             else:
                 res = dbpost.db_postprocess_reference(prob, mask, cfg.db, scale, valid)
                 db.boxes_host, db.nbox_host, db.event = res, None, None
+                db.fig_host = db.nfig_host = None
+                if figs:
+                    db.fig_host = dbpost.db_postprocess_reference(fprob, fmask, cfg.fig_db, scale * 4.0, (valid + 3) // 4)
                 db.keep = None
             db.srcs = srcs
         return db
@@ -256,51 +307,84 @@ class OcrEngine:
         out = rs.resample_items_gpu(dev, len(regions), Hd, Wd, mean, std)
         return out
 
-    def _det_boxes(self, db: _DetBatch) -> List[np.ndarray]:
-        """Wait for the detector of this batch and return per-page boxes in reading order."""
+    def _det_boxes(self, db: _DetBatch) -> List[Tuple[np.ndarray, np.ndarray]]:
+        """Wait for the detector of this batch.  Per page: (lines [n, 7] = x0, y0, x1, y1, score, block, angle in
+        reading order, figures [m, 5] = x0, y0, x1, y1, position in the reading sequence)."""
+        cfg = self.cfg
+        nfig = None
         if db.event is not None:
             db.event.synchronize()
             nb = db.nbox_host.numpy()
             bx = db.boxes_host.numpy()
-            res = [bx[b, : min(int(nb[b]), self.cfg.db.max_boxes)].copy() for b in range(len(db.pages))]
+            res = [bx[b, : min(int(nb[b]), cfg.db.max_boxes)].copy() for b in range(len(db.pages))]
+            figs = None
+            if db.fig_host is not None:
+                nfig, fx = db.nfig_host.numpy(), db.fig_host.numpy()
+                figs = [fx[b, : min(int(nfig[b]), cfg.fig_db.max_boxes), :4].copy() for b in range(len(db.pages))]
         else:
             res = db.boxes_host
+            figs = None if db.fig_host is None else [np.asarray(f, np.float32).reshape(-1, 8)[:, :4] for f in db.fig_host]
         out = []
-        for r, p in zip(res, db.pages):
-            # reading order by layout analysis (columns, headings, header / footer); block id rides in column 5
-            r = np.asarray(r, dtype=np.float32).reshape(-1, r.shape[1] if r.ndim == 2 and r.shape[1] else 5)
-            if r.shape[0] == 0:
-                out.append(np.zeros((0, 6), np.float32))
+        for pi, (r, p) in enumerate(zip(res, db.pages)):
+            r = np.asarray(r, dtype=np.float32)
+            r = r.reshape(-1, r.shape[1] if r.ndim == 2 and r.shape[1] else 8)
+            fg = np.zeros((0, 4), np.float32)
+            if figs is not None and figs[pi].shape[0]:
+                f = figs[pi]
+                big = (np.minimum(f[:, 2] - f[:, 0], f[:, 3] - f[:, 1]) >= cfg.fig_min_side_px)
+                f = f[big]
+                if f.shape[0] > cfg.max_figures_per_page:
+                    area = (f[:, 2] - f[:, 0]) * (f[:, 3] - f[:, 1])
+                    f = f[np.argsort(-area)[: cfg.max_figures_per_page]]
+                fg = f
+            if r.shape[0] and fg.shape[0]:
+                # what the detector reads inside a figure (axis labels, legends) is part of the figure, not of the text
+                cx, cy = 0.5 * (r[:, 0] + r[:, 2]), 0.5 * (r[:, 1] + r[:, 3])
+                inside = ((cx[:, None] >= fg[None, :, 0]) & (cx[:, None] <= fg[None, :, 2]) &
+                          (cy[:, None] >= fg[None, :, 1]) & (cy[:, None] <= fg[None, :, 3])).any(1)
+                r = r[~inside]
+            if r.shape[0] == 0 and fg.shape[0] == 0:
+                out.append((np.zeros((0, 7), np.float32), np.zeros((0, 5), np.float32)))
                 continue
-            order, block, _ = layout.order_page_native(r[:, :4], float(p.hw[0]))
-            cols = r[order]
-            if cols.shape[1] < 5:
-                cols = np.concatenate([cols, np.ones((cols.shape[0], 1), np.float32)], 1)
-            out.append(np.concatenate([cols[:, :5], block[:, None].astype(np.float32)], 1))
+            # reading order by layout analysis (columns, headings, header / footer, figures as obstacles), in the
+            # frame of the upright page when the scan is skewed
+            ang = r[:, 6] if r.shape[1] > 6 else np.zeros((r.shape[0],), np.float32)
+            b4, _ = deskewed_boxes(r[:, :4], ang, p.hw)
+            order, block, kind = layout.order_page_native(b4, float(p.hw[0]), fg if fg.shape[0] else None)
+            n = r.shape[0]
+            is_line = order < n
+            lo = order[is_line]
+            score = r[lo, 4:5] if r.shape[1] > 4 else np.ones((lo.size, 1), np.float32)
+            lines = np.concatenate([r[lo, :4], score, block[is_line][:, None].astype(np.float32), ang[lo][:, None]], 1)
+            pos = np.nonzero(~is_line)[0]
+            fo = np.concatenate([fg[order[pos] - n], pos[:, None].astype(np.float32)], 1) if pos.size else np.zeros((0, 5), np.float32)
+            out.append((lines.astype(np.float32), fo.astype(np.float32)))
         return out
 
     # ------------------------------------------------------------------ recognition stage
-    def _plan_crops(self, db: _DetBatch, det_boxes: List[np.ndarray]):
-        """Host side of N7: choose boxes per page, compute crop geometry, group by width bucket."""
+    def _plan_crops(self, db: _DetBatch, det_boxes):
+        """Host side of N7: choose boxes per page, compute crop geometry, group by width bucket.  ``boxes`` carries
+        the line angle in column 4."""
         cfg = self.cfg
         per_page = []
         all_boxes, all_page = [], []
-        for pi, (p, bx) in enumerate(zip(db.pages, det_boxes)):
+        for pi, (p, (bx, fg)) in enumerate(zip(db.pages, det_boxes)):
             n_det = int(bx.shape[0])
             used_prior = False
-            b4 = bx[:, :4] if n_det else np.zeros((0, 4), np.float32)
-            blk = bx[:, 5].astype(np.int32) if n_det and bx.shape[1] > 5 else np.zeros((b4.shape[0],), np.int32)
+            b5 = bx[:, [0, 1, 2, 3, 6]] if n_det else np.zeros((0, 5), np.float32)
+            blk = bx[:, 5].astype(np.int32) if n_det else np.zeros((0,), np.int32)
             if p.layout_prior is not None and not self._detections_usable(bx, p):
                 b4 = np.asarray(p.layout_prior, dtype=np.float32).reshape(-1, 4)
                 order, blk, _ = layout.order_page_native(b4, float(p.hw[0]))
-                b4 = b4[order]
+                b5 = np.concatenate([b4[order], np.zeros((b4.shape[0], 1), np.float32)], 1)
                 used_prior = True
-            b4 = b4[: cfg.max_lines_per_page]
+                fg = fg[:0]
+            b5 = b5[: cfg.max_lines_per_page]
             blk = blk[: cfg.max_lines_per_page]
-            per_page.append((n_det, used_prior, b4, blk))
-            all_boxes.append(b4)
-            all_page.append(np.full((b4.shape[0],), pi, dtype=np.int32))
-        boxes = np.concatenate(all_boxes, 0) if all_boxes else np.zeros((0, 4), np.float32)
+            per_page.append((n_det, used_prior, b5, blk, fg))
+            all_boxes.append(b5)
+            all_page.append(np.full((b5.shape[0],), pi, dtype=np.int32))
+        boxes = np.concatenate(all_boxes, 0) if all_boxes else np.zeros((0, 5), np.float32)
         page_of = np.concatenate(all_page, 0) if all_page else np.zeros((0,), np.int32)
         w = boxes[:, 2] - boxes[:, 0]
         h = boxes[:, 3] - boxes[:, 1]
@@ -330,9 +414,13 @@ class OcrEngine:
         rb.results = (per_page, boxes, page_of, ok)
         rb.groups = []
         rb.keep = []
+        rb.fig_crops = self._fetch_figures(db, per_page)
         idx_all = np.nonzero(ok)[0]
         if idx_all.size == 0:
             rb.event = None
+            if rb.fig_crops and self.on_gpu:
+                rb.event = torch.cuda.Event()
+                rb.event.record(db.stream)
             return rb
         # source pointer / dims per page
         ptrs = np.array([s.data_ptr() for s in db.srcs], dtype=np.uint64)
@@ -367,8 +455,8 @@ class OcrEngine:
                             out = self._rec_gpu(items, lens_all[ids], wb, db.slot, used_graphs)
                         else:
                             regions = [
-                                rs.Region(db.srcs[page_of[i]], tuple(float(v) for v in boxes[i]), cfg.rec_height,
-                                          int(out_w[i]), int(rot[i])) for i in ids
+                                rs.Region(db.srcs[page_of[i]], tuple(float(v) for v in boxes[i, :4]), cfg.rec_height,
+                                          int(out_w[i]), int(rot[i]), float(boxes[i, 4])) for i in ids
                             ]
                             x = rs.resample_regions(regions, cfg.rec_height, wb, rs.HALF_MEAN, rs.HALF_STD)
                             out = self.rec.infer(x, torch.from_numpy(lens_all[ids]))
@@ -396,7 +484,8 @@ class OcrEngine:
                 x = rs.resample_items_gpu(dev, ids.size, S, S, rs.HALF_MEAN, rs.HALF_STD)
                 rb.keep.append((host, dev))
             else:
-                regions = [rs.Region(db.srcs[page_of[i]], tuple(float(v) for v in boxes[i]), S, S, int(rot[i])) for i in ids]
+                regions = [rs.Region(db.srcs[page_of[i]], tuple(float(v) for v in boxes[i, :4]), S, S, int(rot[i]),
+                                     float(boxes[i, 4])) for i in ids]
                 x = rs.resample_regions(regions, S, S, rs.HALF_MEAN, rs.HALF_STD)
             toks, conf = self.rec.generate(x, max_len=cfg.trocr_max_tokens, use_graph=cfg.use_hip_graphs)
             if self.on_gpu:
@@ -414,6 +503,28 @@ class OcrEngine:
         else:
             rb.event = None
 
+    def _fetch_figures(self, db: _DetBatch, per_page) -> Dict[Tuple[int, int], torch.Tensor]:
+        """Start the device-to-host copies of the figure crops of this batch (page raster pixels, full resolution)."""
+        crops: Dict[Tuple[int, int], torch.Tensor] = {}
+        ctx = torch.cuda.stream(db.stream) if self.on_gpu else _null_ctx()
+        with ctx:
+            for pi, (_, _, _, _, fg) in enumerate(per_page):
+                src = db.srcs[pi]
+                Hs, Ws = int(src.shape[0]), int(src.shape[1])
+                for k in range(fg.shape[0]):
+                    x0, y0 = max(0, int(np.floor(fg[k, 0]))), max(0, int(np.floor(fg[k, 1])))
+                    x1, y1 = min(Ws, int(np.ceil(fg[k, 2]))), min(Hs, int(np.ceil(fg[k, 3])))
+                    if x1 - x0 < 2 or y1 - y0 < 2:
+                        continue
+                    view = src[y0:y1, x0:x1]
+                    if self.on_gpu:
+                        host = torch.empty(view.shape, dtype=torch.uint8, pin_memory=True)
+                        host.copy_(view, non_blocking=True)
+                    else:
+                        host = view.clone()
+                    crops[(pi, k)] = host
+        return crops
+
     def _crop_items(self, ids, boxes, page_of, rot, out_w, src, out_h: Optional[int] = None) -> np.ndarray:
         ptrs, Hs, Ws, Cs, Ps = src
         items = np.zeros(ids.size, dtype=rs.ITEM_DTYPE)
@@ -423,6 +534,7 @@ class OcrEngine:
         items["pitch"] = Ps[pg]
         items["x0"], items["y0"] = boxes[ids, 0], boxes[ids, 1]
         items["x1"], items["y1"] = boxes[ids, 2], boxes[ids, 3]
+        items["angle"] = boxes[ids, 4]
         items["out_h"], items["out_w"] = (out_h or self.cfg.rec_height), out_w[ids]
         return items
 
@@ -514,13 +626,18 @@ class OcrEngine:
             confs[ids] = cf
         results = []
         pos = 0
-        for p, (n_det, used_prior, b4, blk) in zip(rb.det.pages, per_page):
+        for pi, (p, (n_det, used_prior, b4, blk, fg)) in enumerate(zip(rb.det.pages, per_page)):
             r = PageResult(p.doc_id, p.page_index, p.hw[1], p.hw[0],
                            n_detected=n_det, used_layout_prior=used_prior)
             for k in range(b4.shape[0]):
                 gi = pos + k
                 if ok[gi]:
-                    r.lines.append(TextLine(tuple(float(v) for v in b4[k]), texts[gi], float(confs[gi]), int(blk[k])))
+                    r.lines.append(TextLine(tuple(float(v) for v in b4[k, :4]), texts[gi], float(confs[gi]), int(blk[k]),
+                                            float(b4[k, 4])))
+            for k in range(fg.shape[0]):
+                crop = rb.fig_crops.get((pi, k))
+                if crop is not None:
+                    r.figures.append(Figure(tuple(float(v) for v in fg[k, :4]), int(fg[k, 4]), crop.numpy()))
             pos += b4.shape[0]
             self.lines_done += len(r.lines)
             results.append(r)

@@ -1,14 +1,20 @@
-"""Teach the random-init detector and recognizer to read the synthetic page family.
+"""Teach the detector and recognizer to read synthetic scanned pages.
 
 No dataset or checkpoint is reachable offline, so the only way to show that upload -> detect -> crop ->
-recognise -> decode really produces the text on the page is to train both models on pages from
-``pdf.synth.render_page`` and evaluate on unseen seeds.  One script, one GPU, a few minutes:
+recognise -> decode really produces the text on the page is to train both models on generated pages and evaluate
+on pages the training never saw: other seeds, and FONTS that are held out entirely (``synth.HELD_OUT_FONTS``).
+One script, one GPU:
 
-* a background producer renders fresh pages on host threads (PIL releases the GIL) and uploads them;
+* a background producer renders fresh pages on host threads (PIL releases the GIL) and uploads them: mostly
+  ``synth.render_layout_page`` (one or two columns, titles, running header / footer, figures; one of
+  ``synth.TRAIN_FONTS`` per page; skew up to +-5 degrees; blur, sensor noise, contrast and JPEG-quality jitter),
+  the rest the plain single-column ``render_page`` family the benchmark uses;
 * DBNet step: the page is shrunk to detector scale with the *inference* resample kernel, random crops,
-  target = line boxes shrunk by the exact inverse of the serving unclip, loss = balanced BCE + dice;
-* CRNN step: line crops are cut from the full-resolution page with the *inference* crop kernel (so training
-  sees exactly the serving distribution), sorted into width buckets, CTC loss from the fused HIP kernel;
+  text target = the (slanted) line rectangles shrunk by the exact inverse of the serving unclip, figure target =
+  the figure rectangles at 1/4 scale for the block head, loss = balanced BCE + dice on both;
+* CRNN step: line crops are cut from the full-resolution page with the *inference* affine crop kernel (so
+  training sees exactly the serving distribution, slant and all), sorted into width buckets, CTC loss from the
+  fused HIP kernel;
 * both use the flat-bucket fused AdamW; weights are saved as bf16 safetensors for ``OCR_WEIGHTS_DIR``;
 * evaluation runs held-out pages through the real ``OcrEngine`` (detector boxes, not ground truth) and
   reports detection recall and character error rate.
@@ -37,11 +43,40 @@ from ..pdf import synth
 from .trainer import _edit_distance
 
 
+def augment_scan(pg: np.ndarray, rng: np.random.Generator) -> np.ndarray:
+    """Contrast / brightness jitter and, half of the time, a JPEG round trip at a random quality."""
+    import io
+
+    from PIL import Image
+
+    c, b = float(rng.uniform(0.7, 1.15)), float(rng.uniform(-18, 10))
+    out = np.clip((pg.astype(np.float32) - 128.0) * c + 128.0 + b, 0, 255).astype(np.uint8)
+    if rng.random() < 0.5:
+        buf = io.BytesIO()
+        Image.fromarray(out).save(buf, format="JPEG", quality=int(rng.integers(35, 95)))
+        out = np.asarray(Image.open(io.BytesIO(buf.getvalue())))
+    return np.ascontiguousarray(out)
+
+
+def render_training_page(seed: int, fonts=None, plain_share: float = 0.2, max_skew: float = 5.0):
+    """One page of the training distribution (see the module docstring) and its truth."""
+    rng = np.random.default_rng(seed)
+    if rng.random() < plain_share:
+        pg, truth = synth.render_page(seed, font_px=int(rng.integers(34, 50)), noise=float(rng.uniform(0.5, 4.0)))
+        return pg, truth
+    skew = float(rng.uniform(-max_skew, max_skew)) if rng.random() < 0.7 else 0.0
+    blur = float(rng.uniform(0.3, 1.1)) if rng.random() < 0.4 else 0.0
+    pg, truth = synth.render_layout_page(seed, fonts=fonts or synth.TRAIN_FONTS, skew=skew, blur=blur,
+                                         noise=float(rng.uniform(0.5, 5.0)))
+    return augment_scan(pg, rng), truth
+
+
 class PageProducer:
     """Renders pages on host threads and keeps a bounded queue of (uint8 page tensor on device, truth)."""
 
-    def __init__(self, device, threads: int = 6, depth: int = 24, seed0: int = 100_000):
+    def __init__(self, device, threads: int = 6, depth: int = 24, seed0: int = 100_000, fonts=None):
         self.device = device
+        self.fonts = fonts
         self.q: "queue.Queue" = queue.Queue(maxsize=depth)
         self._seed = seed0
         self._lock = threading.Lock()
@@ -55,12 +90,13 @@ class PageProducer:
             with self._lock:
                 self._seed += 1
                 seed = self._seed
-            rng = np.random.default_rng(seed)
-            pg, truth = synth.render_page(seed, font_px=int(rng.integers(34, 50)), noise=float(rng.uniform(0.5, 4.0)))
-            try:
-                self.q.put((torch.from_numpy(pg), truth), timeout=1.0)
-            except queue.Full:
-                continue
+            pg, truth = render_training_page(seed, self.fonts)
+            while not self._stop.is_set():
+                try:
+                    self.q.put((torch.from_numpy(pg), truth), timeout=1.0)
+                    break
+                except queue.Full:
+                    continue
 
     def get(self) -> Tuple[torch.Tensor, synth.PageTruth]:
         pg, truth = self.q.get()
@@ -68,6 +104,25 @@ class PageProducer:
 
     def stop(self):
         self._stop.set()
+
+
+def line_rects(truth: synth.PageTruth, hw: Tuple[int, int]) -> np.ndarray:
+    """Text lines of a (possibly skewed) page as [n, 5] cx, cy, w, h, angle; angle in radians in the crop kernel's
+    sense (the line runs along (cos, sin) in image coordinates, y down) - the opposite sign of the page's
+    counter-clockwise skew."""
+    r = truth.rotated_rects((hw[1], hw[0])).astype(np.float64)
+    r[:, 4] = -np.deg2rad(r[:, 4])
+    return r
+
+
+def rect_corners(r: np.ndarray) -> np.ndarray:
+    """[n, 5] cx, cy, w, h, angle -> [n, 4, 2] corner points."""
+    c, s_ = np.cos(r[:, 4]), np.sin(r[:, 4])
+    ux, uy = 0.5 * r[:, 2] * c, 0.5 * r[:, 2] * s_
+    vx, vy = -0.5 * r[:, 3] * s_, 0.5 * r[:, 3] * c
+    cx, cy = r[:, 0], r[:, 1]
+    return np.stack([np.stack([cx - ux - vx, cy - uy - vy], 1), np.stack([cx + ux - vx, cy + uy - vy], 1),
+                     np.stack([cx + ux + vx, cy + uy + vy], 1), np.stack([cx - ux + vx, cy - uy + vy], 1)], 1)
 
 
 def shrink_boxes(boxes: np.ndarray, unclip_ratio: float = 1.5) -> np.ndarray:
@@ -87,26 +142,54 @@ def shrink_boxes(boxes: np.ndarray, unclip_ratio: float = 1.5) -> np.ndarray:
     return out
 
 
+def _raster_polys(polys: np.ndarray, W: int, H: int) -> np.ndarray:
+    from PIL import Image, ImageDraw
+
+    im = Image.new("L", (W, H), 0)
+    d = ImageDraw.Draw(im)
+    for q in polys:
+        d.polygon([(float(x), float(y)) for x, y in q], fill=1)
+    return np.asarray(im, dtype=np.uint8)
+
+
+def det_targets(truth: synth.PageTruth, hw: Tuple[int, int], scale: float, Hd: int, Wd: int,
+                unclip_ratio: float = 1.5) -> Tuple[np.ndarray, np.ndarray]:
+    """-> (text kernel mask [Hd, Wd], figure mask [Hd/4, Wd/4]) at detector scale."""
+    r = line_rects(truth, hw)
+    if r.shape[0]:
+        up = np.stack([-0.5 * r[:, 2], -0.5 * r[:, 3], 0.5 * r[:, 2], 0.5 * r[:, 3]], 1)
+        sh = shrink_boxes(up, unclip_ratio)
+        r = r.copy()
+        r[:, 2], r[:, 3] = sh[:, 2] - sh[:, 0], sh[:, 3] - sh[:, 1]
+        r[:, :4] *= scale
+    text = _raster_polys(rect_corners(r), Wd, Hd) if r.shape[0] else np.zeros((Hd, Wd), np.uint8)
+    fig = np.zeros((Hd // 4, Wd // 4), np.uint8)
+    if truth.figures.shape[0]:
+        f = synth.rotate_boxes(truth.figures, truth.angle, (hw[1], hw[0])).astype(np.float64)
+        f[:, 4] = -np.deg2rad(f[:, 4])
+        f[:, :4] *= scale / 4.0
+        fig = _raster_polys(rect_corners(f), Wd // 4, Hd // 4)
+    return text, fig
+
+
 def det_batch(pages, device, Hd=1344, Wd=960, crop=(640, 640), per_page=2):
-    """-> x [N,3,h,w] f32 normalised (detector scale), target mask [N,h,w]."""
-    xs, ts = [], []
+    """-> x [N,3,h,w] f32 normalised (detector scale), text target [N,h,w], figure target [N,h/4,w/4]."""
+    xs, ts, fs = [], [], []
     for img, truth in pages:
         H, W = img.shape
         oh, ow = Hd, int(round(W * Hd / H))
         x = rs.resample_regions([rs.Region(img, (0.0, 0.0, float(W), float(H)), oh, ow)], Hd, Wd)[0]   # [Hd,Wd,8] bf16
         x = x[..., :3].permute(2, 0, 1).float()
-        sb = shrink_boxes(truth.boxes) * (oh / H)
-        t = torch.zeros((Hd, Wd), dtype=torch.float32)
-        for b in sb:
-            x0, y0, x1, y1 = [int(round(v)) for v in b]
-            t[max(y0, 0):max(y1, y0 + 1), max(x0, 0):max(x1, x0 + 1)] = 1.0
-        t = t.to(device)
+        tm, fm = det_targets(truth, (H, W), oh / H, Hd, Wd)
+        t = torch.from_numpy(tm).to(device).float()
+        f = torch.from_numpy(fm).to(device).float()
         for _ in range(per_page):
-            cy = np.random.randint(0, Hd - crop[0] + 1)
-            cx = np.random.randint(0, Wd - crop[1] + 1)
+            cy = 32 * np.random.randint(0, (Hd - crop[0]) // 32 + 1)
+            cx = 32 * np.random.randint(0, (Wd - crop[1]) // 32 + 1)
             xs.append(x[:, cy:cy + crop[0], cx:cx + crop[1]])
             ts.append(t[cy:cy + crop[0], cx:cx + crop[1]])
-    return torch.stack(xs), torch.stack(ts)
+            fs.append(f[cy // 4:(cy + crop[0]) // 4, cx // 4:(cx + crop[1]) // 4])
+    return torch.stack(xs), torch.stack(ts), torch.stack(fs)
 
 
 def det_loss(prob: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
@@ -121,23 +204,38 @@ def det_loss(prob: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     return l_bce + dice
 
 
+def fig_loss(logit: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """Block head: balanced BCE on logits + dice on the sigmoid."""
+    logit = logit.float()
+    pos = target > 0.5
+    bce = F.binary_cross_entropy_with_logits(logit, target, reduction="none")
+    l_bce = bce[pos].sum() / pos.sum().clamp(min=1) + bce[~pos].sum() / (~pos).sum().clamp(min=1)
+    p = torch.sigmoid(logit)
+    dice = 1 - (2 * (p * target).sum() + 1.0) / (p.sum() + target.sum() + 1.0)
+    return l_bce + dice
+
+
 REC_BUCKETS = (1280, 2048)      # static training shapes: every new conv shape costs MIOpen a kernel build
 
 
-def rec_batch(pages, model: CRNN, device, max_lines=64, jitter=0.12):
+def rec_batch(pages, model: CRNN, device, max_lines=64, jitter=0.12, angle_jitter=0.007):
     """Crop lines with the inference kernel. -> x [N,3,48,Wb] f32, in_lens, targets, tgt_lens, texts.
     N and Wb are static (one of REC_BUCKETS, exactly ``max_lines`` rows) so the autograd path sees two shapes."""
     regions, texts = [], []
     for img, truth in pages:
         H, W = img.shape
-        for b, t in zip(truth.boxes, truth.texts):
-            # detector boxes are not pixel-exact: jitter every side by a fraction of the line height
-            j = (np.random.uniform(-jitter, jitter, size=4) * (b[3] - b[1])).astype(np.float32)
-            x0, y0, x1, y1 = np.clip(b + j, 0, [W, H, W, H])
-            if x1 - x0 < 8 or y1 - y0 < 8:
+        rects = line_rects(truth, (H, W))
+        for r, t in zip(rects, truth.texts):
+            # detector boxes are not pixel-exact: jitter every side by a fraction of the line height, and the angle
+            # by what the second-moment estimate is off on a short line
+            j = np.random.uniform(-jitter, jitter, size=4) * r[3]
+            cx, cy = r[0] + 0.5 * (j[0] + j[2]), r[1] + 0.5 * (j[1] + j[3])
+            w, h = r[2] + (j[2] - j[0]), r[3] + (j[3] - j[1])
+            if w < 8 or h < 8:
                 continue
-            ow = int(np.clip(round((x1 - x0) * 48.0 / (y1 - y0)), 8, REC_BUCKETS[-1]))
-            regions.append((img, (float(x0), float(y0), float(x1), float(y1)), ow))
+            ang = float(r[4] + np.random.uniform(-angle_jitter, angle_jitter)) if r[4] != 0.0 else 0.0
+            ow = int(np.clip(round(w * 48.0 / h), 8, REC_BUCKETS[-1]))
+            regions.append((img, (float(cx - 0.5 * w), float(cy - 0.5 * h), float(cx + 0.5 * w), float(cy + 0.5 * h)), ow, ang))
             texts.append(t)
     widths = np.array([r[2] for r in regions])
     Wb = REC_BUCKETS[0] if np.random.rand() < float((widths <= REC_BUCKETS[0]).mean()) else REC_BUCKETS[-1]
@@ -145,8 +243,8 @@ def rec_batch(pages, model: CRNN, device, max_lines=64, jitter=0.12):
     if pool.size == 0:
         pool, Wb = np.arange(len(regions)), REC_BUCKETS[-1]
     sel = np.random.choice(pool, size=max_lines, replace=pool.size < max_lines)
-    x = rs.resample_regions([rs.Region(regions[i][0], regions[i][1], 48, regions[i][2]) for i in sel], 48, Wb,
-                            rs.HALF_MEAN, rs.HALF_STD)
+    x = rs.resample_regions([rs.Region(regions[i][0], regions[i][1], 48, regions[i][2], 0, regions[i][3]) for i in sel],
+                            48, Wb, rs.HALF_MEAN, rs.HALF_STD)
     x = x[..., :3].permute(0, 3, 1, 2).float()
     in_lens = torch.tensor([max((regions[i][2] + 3) // 4, 1) for i in sel])
     tg, tl, tx = [], [], []
@@ -184,44 +282,83 @@ def save_bf16(model, path):
     os.replace(tmp, path)
 
 
-def evaluate(det, rec, device, seeds, verbose=False):
-    """Held-out pages through the real inference engine (detector boxes, GPU post-process, crops, CRNN, CTC)."""
-    from ..runtime.engine import EngineConfig, OcrEngine, PageImage
+def evaluate_pages(engine, pages_truth, verbose=False):
+    """Pages through the real inference engine (detector boxes, GPU post-process, layout order, affine crops, CRNN,
+    CTC).  Two error rates: per line (a truth line is matched to the detected line whose centre is closest, within
+    half a line height) and per page (the engine's text in ITS reading order against the truth in reading order, so
+    a column read across counts as errors)."""
+    from ..runtime.engine import PageImage
 
-    eng = OcrEngine(device, det, rec, EngineConfig(max_batch_pages=4))
-    pages, truths = [], []
-    for s in seeds:
-        pg, tr = synth.render_page(s)
-        pages.append(PageImage(torch.from_numpy(pg).pin_memory() if device.type == "cuda" else torch.from_numpy(pg), "eval", len(pages)))
-        truths.append(tr)
-    res = eng.process_pages(pages)
-    n_truth = n_found = 0
-    ed = nchar = 0
-    for r, tr in zip(res, truths):
+    dev = engine.device
+    pages = [PageImage(torch.from_numpy(pg).pin_memory() if dev.type == "cuda" else torch.from_numpy(pg), "eval", k)
+             for k, (pg, _) in enumerate(pages_truth)]
+    res = engine.process_pages(pages)
+    n_truth = n_found = ed = nchar = ed_page = 0
+    fig_truth = fig_found = 0
+    for r, (pg, tr) in zip(res, pages_truth):
+        rects = line_rects(tr, pg.shape)
+        lc = np.array([[0.5 * (l.box[0] + l.box[2]), 0.5 * (l.box[1] + l.box[3])] for l in r.lines], np.float64).reshape(-1, 2)
         used = set()
-        for b, t in zip(tr.boxes, tr.texts):
+        for rc, t in zip(rects, tr.texts):
             n_truth += 1
-            best, bi = 0.0, -1
-            for k, ln in enumerate(r.lines):
-                ix = max(0.0, min(b[2], ln.box[2]) - max(b[0], ln.box[0])) * max(0.0, min(b[3], ln.box[3]) - max(b[1], ln.box[1]))
-                un = (b[2] - b[0]) * (b[3] - b[1]) + (ln.box[2] - ln.box[0]) * (ln.box[3] - ln.box[1]) - ix
-                iou = ix / max(un, 1e-6)
-                if iou > best:
-                    best, bi = iou, k
-            if best >= 0.5 and bi not in used:
-                used.add(bi)
+            nchar += len(t)
+            if lc.shape[0] == 0:
+                ed += len(t)
+                continue
+            dist = np.hypot(lc[:, 0] - rc[0], lc[:, 1] - rc[1])
+            k = int(np.argmin(dist))
+            lw = r.lines[k].box[2] - r.lines[k].box[0]
+            if dist[k] <= 0.5 * rc[3] + 0.05 * rc[2] and k not in used and 0.8 * rc[2] <= lw <= 1.25 * rc[2] + 2 * rc[3]:
+                used.add(k)
                 n_found += 1
-                ed += _edit_distance(r.lines[bi].text, t)
+                ed += _edit_distance(r.lines[k].text, t)
             else:
                 ed += len(t)
-            nchar += len(t)
+        ed_page += _edit_distance("\n".join(l.text for l in r.lines), "\n".join(tr.texts))
+        fig_truth += tr.figures.shape[0]
+        fig_found += min(len(r.figures), tr.figures.shape[0])
         if verbose and r.lines:
-            print("   sample:", repr(r.lines[0].text), "| truth:", repr(tr.texts[0]))
+            print("   sample:", repr(r.lines[0].text), "| truth:", repr(tr.texts[0]), flush=True)
+    return {"det_recall": n_found / max(n_truth, 1), "cer": ed / max(nchar, 1), "page_cer": ed_page / max(nchar, 1),
+            "boxes_per_page": float(np.mean([len(r.lines) for r in res])),
+            "truth_per_page": float(np.mean([len(t.texts) for _, t in pages_truth])),
+            "figures_found": fig_found, "figures_truth": fig_truth}
+
+
+def held_out_pages(seeds, skew=3.0, fonts=None):
+    """Evaluation pages in fonts the training never drew, alternately skewed by +-``skew`` degrees."""
+    fonts = fonts or synth.HELD_OUT_FONTS
+    out = []
+    for k, sd in enumerate(seeds):
+        out.append(synth.render_layout_page(sd, fonts=fonts, layout=synth.LAYOUTS[k % len(synth.LAYOUTS)],
+                                            skew=skew * (1 if k % 2 == 0 else -1), noise=2.0))
+    return out
+
+
+def evaluate(det, rec, device, seeds, verbose=False):
+    """Three held-out sets: the benchmark's page family (unseen seeds), layout pages in the training fonts, layout
+    pages in held-out fonts at +-3 degrees of skew."""
+    from ..runtime.engine import EngineConfig, OcrEngine
+
+    eng = OcrEngine(device, det, rec, EngineConfig(max_batch_pages=4))
+    out = {}
+    out["plain"] = evaluate_pages(eng, [synth.render_page(sd) for sd in seeds[:4]], verbose)
+    out["layout_train_fonts"] = evaluate_pages(eng, [render_training_page(sd, plain_share=0.0) for sd in seeds], verbose)
+    out["held_out_fonts_skew3"] = evaluate_pages(eng, held_out_pages(seeds), verbose)
     det.train()
     rec.train()
-    return {"det_recall": n_found / max(n_truth, 1), "cer": ed / max(nchar, 1),
-            "boxes_per_page": float(np.mean([len(r.lines) for r in res])),
-            "truth_per_page": float(np.mean([len(t.texts) for t in truths]))}
+    return out
+
+
+def write_meta(out_dir: str, steps: int, ev, log) -> None:
+    """``train_meta.json``: what the weights were trained on (fonts drawn, fonts never drawn) and how they score."""
+    json.dump({"steps": steps, "eval": ev, "log": log[-20:],
+               "train_fonts": synth.available_fonts(synth.TRAIN_FONTS),
+               "held_out_fonts": synth.available_fonts(synth.HELD_OUT_FONTS),
+               "augmentation": {"skew_deg": 5.0, "blur_sigma": [0.3, 1.1], "noise_sigma": [0.5, 5.0],
+                                "contrast": [0.7, 1.15], "jpeg_quality": [35, 95], "font_px": [30, 50],
+                                "layouts": list(synth.LAYOUTS) + ["plain"]}},
+              open(os.path.join(out_dir, "train_meta.json"), "w"), indent=1)
 
 
 def main(argv=None) -> int:
@@ -233,7 +370,8 @@ def main(argv=None) -> int:
     ap.add_argument("--resume", action="store_true")
     ap.add_argument("--eval-every", type=int, default=500)
     ap.add_argument("--time-limit", type=float, default=900.0, help="stop cleanly (and save) after this many seconds")
-    ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--threads", type=int, default=12)
+    ap.add_argument("--init", default="", help="directory with weights to start from (step count restarts at 0)")
     args = ap.parse_args(argv)
     device = torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
     torch.manual_seed(0)
@@ -242,10 +380,16 @@ def main(argv=None) -> int:
     os.makedirs(args.out, exist_ok=True)
     dp, rp = os.path.join(args.out, "dbnet.safetensors"), os.path.join(args.out, "crnn.safetensors")
     start = 0
+    if args.init and not (args.resume and os.path.exists(dp)):
+        from ..utils.weights import load_model_weights
+
+        load_model_weights(det, os.path.join(args.init, "dbnet.safetensors"), strict=False)     # no block head in older files
+        load_model_weights(rec, os.path.join(args.init, "crnn.safetensors"))
+        print(f"initialised from {args.init}", flush=True)
     if args.resume and os.path.exists(dp) and os.path.exists(rp):
         from ..utils.weights import load_model_weights
 
-        load_model_weights(det, dp)
+        load_model_weights(det, dp, strict=False)
         load_model_weights(rec, rp)
         meta = os.path.join(args.out, "train_meta.json")
         if os.path.exists(meta):
@@ -270,12 +414,13 @@ def main(argv=None) -> int:
         while it < args.steps and time.perf_counter() - t0 < args.time_limit:
             pages = [prod.get() for _ in range(3)]
             # ---- detector step
-            x, tgt = det_batch(pages, device)
+            x, tgt, ftgt = det_batch(pages, device)
             dopt.zero()
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-                prob = det(x)
+                prob, flogit = det.forward_all(x)
             ld = det_loss(prob, tgt)
-            ld.backward()
+            lf = fig_loss(flogit, ftgt)
+            (ld + 0.5 * lf).backward()
             dopt.step(it, args.steps)
             # ---- recognizer step
             xr, il, tg, tl, _ = rec_batch(pages, rec, device)
@@ -288,7 +433,8 @@ def main(argv=None) -> int:
             ropt.step(it, args.steps)
             it += 1
             if it % 25 == 0:
-                rec_ = {"step": it, "det_loss": round(float(ld), 4), "ctc_per_char": round(float(lr_), 4),
+                rec_ = {"step": it, "det_loss": round(float(ld), 4), "fig_loss": round(float(lf), 4),
+                        "ctc_per_char": round(float(lr_), 4),
                         "elapsed_s": round(time.perf_counter() - t0, 1)}
                 log.append(rec_)
                 print(json.dumps(rec_), flush=True)
@@ -297,14 +443,14 @@ def main(argv=None) -> int:
                 print(json.dumps({"step": it, "eval": ev}), flush=True)
                 save_bf16(det, dp)
                 save_bf16(rec, rp)
-                json.dump({"steps": it, "eval": ev, "log": log[-20:]}, open(os.path.join(args.out, "train_meta.json"), "w"))
+                write_meta(args.out, it, ev, log)
     finally:
         prod.stop()
         alive.set()
-    ev = evaluate(det, rec, device, seeds=[900_001, 900_002, 900_003, 900_004, 900_005, 900_006], verbose=True)
+    ev = evaluate(det, rec, device, seeds=[900_001, 900_002, 900_003, 900_004, 900_005, 900_006, 900_007, 900_008], verbose=True)
     save_bf16(det, dp)
     save_bf16(rec, rp)
-    json.dump({"steps": it, "eval": ev, "log": log[-20:]}, open(os.path.join(args.out, "train_meta.json"), "w"))
+    write_meta(args.out, it, ev, log)
     print(json.dumps({"final_step": it, "eval": ev, "weights": args.out}), flush=True)
     return 0
 

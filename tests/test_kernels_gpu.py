@@ -256,6 +256,74 @@ def test_db_postprocess_matches_scipy():
         np.testing.assert_allclose(o[:, 5], r[:, 5])
 
 
+def _slanted_prob_map(H=320, W=480, seed=3):
+    """Probability map with filled rectangles turned by known angles (what the detector emits for a skewed scan)."""
+    from PIL import Image, ImageDraw
+
+    from distributed_llms_amd.train.page_trainer import rect_corners
+
+    rects = np.array([[240, 40, 400, 18, np.deg2rad(-5.0)], [230, 110, 380, 16, np.deg2rad(3.0)],
+                      [250, 170, 300, 20, np.deg2rad(1.0)], [240, 240, 420, 14, np.deg2rad(8.0)],
+                      [100, 295, 150, 16, 0.0]], dtype=np.float64)
+    im = Image.new("L", (W, H), 0)
+    d = ImageDraw.Draw(im)
+    for q in rect_corners(rects):
+        d.polygon([(float(x), float(y)) for x, y in q], fill=1)
+    m = torch.from_numpy(np.asarray(im, dtype=np.uint8).copy())
+    g = torch.Generator().manual_seed(seed)
+    prob = torch.rand(H, W, generator=g) * 0.2
+    prob[m > 0] = 0.75 + 0.2 * torch.rand(int(m.sum()), generator=g)
+    return prob.to(torch.bfloat16)[None], rects
+
+
+def test_db_postprocess_oriented_boxes_for_slanted_lines():
+    prob, rects = _slanted_prob_map()
+    mask = (prob.float() > 0.3).to(torch.uint8)
+    cfg = dbpost.DBPostConfig(unclip_ratio=1.5)
+    scale = torch.tensor([[2.5, 2.6]], dtype=torch.float32)
+    ref = dbpost.db_postprocess_reference(prob, mask, cfg, scale)[0]
+    ws = dbpost.DBPostWorkspace(1, prob.shape[1], prob.shape[2], cfg, torch.device(DEV))
+    bx, nb = dbpost.db_postprocess_gpu(prob.to(DEV), mask.to(DEV), ws, scale.to(DEV))
+    out = bx[0, : int(nb[0])].cpu().numpy()
+    assert out.shape == ref.shape == (5, 8)
+    o, r = out[np.argsort(out[:, 1])], ref[np.argsort(ref[:, 1])]
+    np.testing.assert_allclose(o[:, :4], r[:, :4], rtol=1e-5, atol=2e-2)
+    np.testing.assert_allclose(o[:, 6], r[:, 6], atol=2e-5)
+    np.testing.assert_allclose(o[:, 5], r[:, 5])
+    # geometry: angle within 0.3 degrees of the truth, size = truth + unclip within ~2 px (det pixels), centre within 1
+    for row, t in zip(o, rects[np.argsort(rects[:, 1])]):
+        d = t[2] * t[3] * 1.5 / (2 * (t[2] + t[3]))
+        want_angle = np.arctan2(np.sin(t[4]) * 2.6, np.cos(t[4]) * 2.5)
+        assert abs(row[6] - want_angle) < np.deg2rad(0.3), (row, t)
+        L, T = (row[2] - row[0]), (row[3] - row[1])
+        assert abs(L / 2.5 - (t[2] + 2 * d)) < 4.5 and abs(T / 2.6 - (t[3] + 2 * d)) < 3.5, (L, T, t, d)
+        assert abs(0.5 * (row[0] + row[2]) / 2.5 - t[0]) < 1.5 and abs(0.5 * (row[1] + row[3]) / 2.6 - t[1]) < 1.5
+
+
+def test_resample_affine_crop_of_slanted_lines():
+    g = torch.Generator().manual_seed(5)
+    page = torch.randint(0, 256, (400, 600), dtype=torch.uint8, generator=g)
+    # smooth it a little so that sub-pixel differences between float32 paths stay small
+    page = torch.nn.functional.avg_pool2d(page[None, None].float(), 3, 1, 1)[0, 0].to(torch.uint8)
+    rgb = torch.randint(0, 256, (120, 200, 3), dtype=torch.uint8, generator=g)
+    regs = [
+        resample.Region(page, (50.0, 100.0, 550.0, 160.0), 48, 400, 0, 0.06),      # shrink 1.25x, 3.4 degrees
+        resample.Region(page, (50.0, 200.0, 550.0, 330.0), 48, 184, 0, -0.09),     # shrink 2.7x: 3 x 3 taps
+        resample.Region(page, (100.0, 50.0, 300.0, 70.0), 48, 480, 0, 0.03),       # enlarge: one tap
+        resample.Region(rgb, (20.0, 30.0, 180.0, 70.0), 32, 128, 0, -0.05),
+        resample.Region(page, (300.0, 40.0, 340.0, 380.0), 48, 408, 1, 0.04),      # tall box, turned 90 degrees too
+        resample.Region(page, (-20.0, -10.0, 200.0, 30.0), 48, 264, 0, 0.08),      # sticks out of the image: clamped
+    ]
+    ref = resample.resample_regions_reference(regs, 48, 480, resample.HALF_MEAN, resample.HALF_STD)
+    dregs = [resample.Region(r.image.to(DEV), r.box, r.out_h, r.out_w, r.rot, r.angle) for r in regs]
+    out = resample.resample_regions(dregs, 48, 480, resample.HALF_MEAN, resample.HALF_STD)
+    _close(out, ref, rtol=1e-2, atol=3e-2)
+    # and the angle does something: the same box without it differs
+    flat = resample.resample_regions([resample.Region(page.to(DEV), regs[0].box, 48, 400)], 48, 480,
+                                     resample.HALF_MEAN, resample.HALF_STD)
+    assert (flat[0].float() - out[0].float()).abs().mean().item() > 0.02
+
+
 def test_db_postprocess_random_noise_components():
     g = torch.Generator().manual_seed(1)
     prob = torch.rand(2, 96, 128, generator=g).to(torch.bfloat16)

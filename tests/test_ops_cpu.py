@@ -87,7 +87,7 @@ def test_dbpost_reference_boxes():
     prob[0, 55:58, 5:50] = 0.4    # below box threshold
     mask = (prob > 0.3).to(torch.uint8)
     res = dbpost.db_postprocess(prob, mask, dbpost.DBPostConfig())
-    assert len(res) == 1 and res[0].shape == (2, 6)
+    assert len(res) == 1 and res[0].shape == (2, 8)
     b0, b1 = res[0]
     # first in reading order: the wide line, unclipped by d = 72*10*1.5 / (2*82)
     d = 72 * 10 * 1.5 / (2 * 82)
