@@ -235,9 +235,13 @@ class TrOCR(nn.Module):
         st.t.add_(1)
 
     @torch.no_grad()
-    def generate(self, x: torch.Tensor, max_len: Optional[int] = None, use_graph: bool = True
-                 ) -> Tuple[torch.Tensor, torch.Tensor]:
-        """x: [B, S, S, 8] bf16 -> (tokens [B, max_len] int32, mean token probability [B])."""
+    def generate(self, x: torch.Tensor, max_len: Optional[int] = None, use_graph: bool = True,
+                 eos_check_every: int = 8) -> Tuple[torch.Tensor, torch.Tensor]:
+        """x: [B, S, S, 8] bf16 -> (tokens [B, max_len] int32, mean token probability [B]).
+
+        Decoding stops as soon as every sequence of the batch has produced ``eos`` (looked at every
+        ``eos_check_every`` steps, one small device-to-host read each); positions after a sequence's ``eos`` are
+        filled with ``pad`` and do not count towards its mean probability.  0 disables the early exit."""
         if self._pk is None:
             self.prepare()
         cfg, pk = self.cfg, self._pk
@@ -258,13 +262,22 @@ class TrOCR(nn.Module):
             st.v_cross[li][:B].copy_(kv[..., cfg.dec_dim :])
         st.tokens.fill_(cfg.bos)
         st.t.zero_()
-        out = torch.empty((max_len, Bb), dtype=torch.int32, device=x.device)
+        out = torch.full((max_len, Bb), cfg.pad, dtype=torch.int32, device=x.device)
         psum = torch.zeros((Bb,), dtype=torch.float32, device=x.device)
+        cnt = torch.zeros((Bb,), dtype=torch.float32, device=x.device)
+        done = torch.zeros((Bb,), dtype=torch.bool, device=x.device)
+        done[B:] = True                                     # padding rows of the batch bucket
         for s in range(max_len):
             g.step()
-            out[s].copy_(st.tokens)
-            psum += st.probs
-        return out[:, :B].t().contiguous(), (psum[:B] / max_len)
+            live = ~done
+            out[s] = torch.where(live, st.tokens, out[s])
+            psum += st.probs * live
+            cnt += live
+            done |= st.tokens == cfg.eos
+            if eos_check_every > 0 and (s + 1) % eos_check_every == 0 and s + 1 < max_len and bool(done.all()):
+                break
+        self.last_decode_steps = s + 1
+        return out[:, :B].t().contiguous(), (psum[:B] / cnt[:B].clamp(min=1.0))
 
     def tokens_to_text(self, tokens: torch.Tensor, vocab=None) -> List[str]:
         """ids -> text through the native byte-level vocabulary (csrc/runtime/bpe_tokenizer.cpp).  Without a

@@ -1,0 +1,112 @@
+"""End-to-end behaviour of the shipped weights (train/page_trainer.py, weights/train_meta.json) on pages the training
+never saw: fonts that were held out entirely, skewed scans, multi-column layouts, figures.  Everything goes through
+the product path (scanned PDF -> DocumentPipeline -> OcrEngine), on the GPU."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from distributed_llms_amd.pdf import synth
+
+pytestmark = pytest.mark.gpu
+WD = Path(__file__).resolve().parents[1] / "weights"
+
+
+@pytest.fixture(scope="module")
+def pipe():
+    from distributed_llms_amd.runtime.document import DocumentPipeline
+    from distributed_llms_amd.runtime.workers import build_engine
+    from distributed_llms_amd.store.results import LocalFileWriter
+
+    if not (WD / "dbnet.safetensors").exists() or not (WD / "crnn.safetensors").exists():
+        pytest.skip("no trained weights shipped")
+    eng = build_engine("cuda:0", {"model": "full", "weights_dir": str(WD), "cfg": dict(max_batch_pages=4)})
+    import tempfile
+
+    d = tempfile.mkdtemp(prefix="dlamd-figs-")
+    p = DocumentPipeline(eng, decode_threads=4, image_writer=LocalFileWriter(d))
+    p._fig_dir = d
+    yield p
+    p.close()
+
+
+def _cer(got: str, want: str) -> float:
+    from distributed_llms_amd.train.trainer import _edit_distance
+
+    return _edit_distance(got, want) / max(len(want), 1)
+
+
+def test_held_out_fonts_and_skew(pipe):
+    """Fonts the training never drew (synth.HELD_OUT_FONTS), pages turned by +-3 degrees: CER under 2 %."""
+    import json
+
+    from distributed_llms_amd.train.page_trainer import evaluate_pages, held_out_pages
+
+    meta = json.loads((WD / "train_meta.json").read_text())
+    assert len(meta["train_fonts"]) >= 8 and set(meta["held_out_fonts"]).isdisjoint(meta["train_fonts"])
+    assert set(synth.available_fonts(synth.HELD_OUT_FONTS)) <= set(meta["held_out_fonts"])
+    pages = held_out_pages([555_001, 555_002, 555_003, 555_004, 555_005, 555_006], skew=3.0)
+    assert {tr.font_names[0] for _, tr in pages} <= set(meta["held_out_fonts"]) and all(abs(abs(tr.angle) - 3.0) < 1e-6 for _, tr in pages)
+    ev = evaluate_pages(pipe.engine, pages)
+    print("held-out fonts, +-3 degrees:", ev)
+    assert ev["det_recall"] > 0.97, ev
+    assert ev["cer"] < 0.02 and ev["page_cer"] < 0.03, ev
+
+
+def test_two_column_scan_reads_column_major(pipe):
+    """A scanned two-column page: ``combined_text`` follows the truth's reading order (header, title, first column
+    top to bottom, second column, footer), line for line."""
+    pg, tr = synth.render_layout_page(424_242, layout="two_col_title", fonts=["DejaVuSerif.ttf"], noise=2.0)
+    doc = pipe.process_pdf(synth.make_scanned_pdf([pg], codec="jpeg", restart_blocks=0), "two-col")
+    assert doc.mode == "ocr"
+    got = [l.text.strip() for l in doc.pages[0].lines]
+    want = [t.strip() for t in tr.texts]
+    assert len(got) == len(want), (len(got), len(want))
+    # line k of the output is line k of the truth (a page read across its columns pairs unrelated lines)
+    per_line = [_cer(g, w) for g, w in zip(got, want)]
+    assert max(per_line) < 0.25 and float(np.mean(per_line)) < 0.02, sorted(per_line)[-5:]
+    # the paragraphs of the combined text, flattened, are the truth's lines in order
+    flat = " ".join(doc.text.split())
+    assert _cer(flat, " ".join(" ".join(want).split())) < 0.02
+    # blocks: lines of the two columns never share a text block
+    xs = np.array([0.5 * (l.box[0] + l.box[2]) for l in doc.pages[0].lines])
+    blk = np.array([l.block for l in doc.pages[0].lines])
+    left, right = set(blk[xs < 0.4 * pg.shape[1]]), set(blk[xs > 0.6 * pg.shape[1]])
+    assert left and right and not (left & right - set(blk[(xs >= 0.4 * pg.shape[1]) & (xs <= 0.6 * pg.shape[1])]))
+
+
+def test_skewed_two_column_scan_keeps_reading_order(pipe):
+    pg, tr = synth.render_layout_page(424_243, layout="two_col", fonts=["DejaVuSans.ttf"], skew=-2.5, noise=2.0)
+    doc = pipe.process_pdf(synth.make_scanned_pdf([pg], codec="jpeg", restart_blocks=0), "two-col-skew")
+    lines = doc.pages[0].lines
+    assert any(abs(l.angle) > 0.02 for l in lines)         # the boxes are oriented ...
+    got, want = "\n".join(l.text.strip() for l in lines), "\n".join(t.strip() for t in tr.texts)
+    assert _cer(got, want) < 0.03, (_cer(got, want), got[:300], want[:300])
+
+
+def test_figure_is_found_kept_out_of_the_text_and_written(pipe):
+    import os
+
+    pg, tr = synth.render_layout_page(424_244, layout="figure", fonts=["STIXGeneral.ttf"], noise=2.0)
+    assert tr.figures.shape[0] == 1
+    doc = pipe.process_pdf(synth.make_scanned_pdf([pg], codec="jpeg", restart_blocks=0), "with figure")
+    page = doc.pages[0]
+    assert len(page.figures) == 1, [f.box for f in page.figures]
+    f, t = page.figures[0], tr.figures[0]
+    ix = max(0.0, min(f.box[2], t[2]) - max(f.box[0], t[0])) * max(0.0, min(f.box[3], t[3]) - max(f.box[1], t[1]))
+    iou = ix / ((f.box[2] - f.box[0]) * (f.box[3] - f.box[1]) + (t[2] - t[0]) * (t[3] - t[1]) - ix)
+    assert iou > 0.7, (f.box, t, iou)
+    # the crop went through the image writer, the content list carries it at its place in the reading sequence
+    assert f.image is None and f.path and os.path.exists(os.path.join(pipe._fig_dir, f.path))
+    from PIL import Image
+
+    im = Image.open(os.path.join(pipe._fig_dir, f.path))
+    assert abs(im.size[0] - (t[2] - t[0])) < 0.2 * (t[2] - t[0])
+    items = doc.content_list
+    kinds = [it["type"] for it in items]
+    assert "image" in kinds and 0 < kinds.index("image") < len(kinds) - 1
+    assert all("img_path" in it for it in items if it["type"] == "image")
+    # text: the figure contributes no lines, the caption and both neighbours are read
+    got, want = "\n".join(l.text.strip() for l in page.lines), "\n".join(s.strip() for s in tr.texts)
+    assert _cer(got, want) < 0.03, (_cer(got, want), got[:300], want[:300])

@@ -110,3 +110,46 @@ def test_gpu_count_never_touches_the_gpu_runtime(tmp_path, monkeypatch):
     assert serve.count_gpus() == 5
     import sys
     assert "torch" not in serve.count_gpus.__code__.co_names
+
+
+def test_image_layout_ships_and_loads_the_trained_weights(tmp_path, monkeypatch):
+    """deploy/Dockerfile copies csrc/, the package, bench files and weights/ into /app and sets no OCR_WEIGHTS_DIR:
+    in that layout ``Settings.from_env()`` must find the weights next to the package and ``make_extractor`` must
+    load them into the engine."""
+    import re
+    import shutil
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    docker = (root / "deploy" / "Dockerfile").read_text()
+    copied = re.findall(r"^COPY\s+(\S+)/\s+\S+/\s*$", docker, flags=re.M)
+    assert "weights" in copied and "distributed_llms_amd" in copied
+    assert "OCR_WEIGHTS_DIR" not in re.sub(r"#.*", "", docker)          # the default lookup is what the image relies on
+    assert (root / "weights" / "dbnet.safetensors").exists() and (root / "weights" / "train_meta.json").exists()
+    app = tmp_path / "app"
+    app.mkdir()
+    for d in copied:
+        if d in ("distributed_llms_amd", "weights"):
+            shutil.copytree(root / d, app / d, ignore=shutil.ignore_patterns("__pycache__"))
+    code = (
+        "import os, torch\n"
+        "from distributed_llms_amd.config import Settings\n"
+        "from distributed_llms_amd.runtime.extractor import make_extractor\n"
+        "from safetensors.torch import load_file as load_state\n"
+        "s = Settings.from_env()\n"
+        "assert s.weights_dir == os.path.join(os.getcwd(), 'weights'), s.weights_dir\n"
+        "ext = make_extractor(s)\n"
+        "eng = ext.pipeline.engine\n"
+        "want = load_state(os.path.join(s.weights_dir, 'crnn.safetensors'))\n"
+        "k = next(k for k in want if k.endswith('fc.weight'))\n"
+        "got = dict(eng.rec.state_dict())[k]\n"
+        "assert torch.equal(got.float().cpu(), want[k].float()), 'recognizer weights were not loaded'\n"
+        "ext.close()\n"
+        "print('WEIGHTS-LOADED')\n"
+    )
+    env = {k: v for k, v in os.environ.items() if not k.startswith("OCR_")}
+    env.update(OCR_NUM_GPUS="0", OCR_STORE="memory", PYTHONPATH=str(app))
+    p = subprocess.run([sys.executable, "-c", code], cwd=app, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "WEIGHTS-LOADED" in p.stdout, p.stderr[-3000:]
