@@ -82,14 +82,20 @@ def main():
     ap.add_argument("--burst-poll-ms", type=float, default=10.0, help="status polling interval of the concurrent clients")
     ap.add_argument("--num-gpus", type=int, default=-1)
     ap.add_argument("--force-pool", action="store_true", help="use the worker-process pool even with one GPU")
+    ap.add_argument("--server", choices=["dlamd", "uvicorn"], default="dlamd",
+                    help="HTTP server in front of the application: api/httpd.py (default) or uvicorn")
     args = ap.parse_args()
 
     # the service runs as its own process, exactly as deployed: uvicorn + the module-level ASGI app
     env = dict(os.environ, OCR_NUM_GPUS=str(args.num_gpus), OCR_OUTPUT_DIR="/tmp/ocr_bench_out",
                OCR_FORCE_POOL="1" if args.force_pool else "0", OCR_DOTENV="/nonexistent")
-    server = subprocess.Popen([sys.executable, "-m", "uvicorn", "distributed_llms_amd.api.asgi:app", "--host", "127.0.0.1",
-                               "--port", str(args.port), "--log-level", "warning"], env=env,
-                              cwd=str(Path(__file__).resolve().parents[1]))
+    if args.server == "uvicorn":
+        cmd = [sys.executable, "-m", "uvicorn", "distributed_llms_amd.api.asgi:app", "--host", "127.0.0.1",
+               "--port", str(args.port), "--log-level", "warning"]
+    else:
+        cmd = [sys.executable, "-m", "distributed_llms_amd.api.httpd", "distributed_llms_amd.api.asgi:app", "--host", "127.0.0.1",
+               "--port", str(args.port)]
+    server = subprocess.Popen(cmd, env=env, cwd=str(Path(__file__).resolve().parents[1]))
     client = Client(args.port)
     for _ in range(1200):
         try:

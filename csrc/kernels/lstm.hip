@@ -510,6 +510,204 @@ __global__ __launch_bounds__(512) void lstm_bidir_kernel3(const bf16_t* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v4 (W_hh 7/8 resident): v3 still pulls 256 KB of W_hh per step through L2 at the ~70 GB/s one CU gets, 3.6 us of
+// its 4.9 us step.  The register file of a CU is 512 KB: with 8 waves (2 per SIMD) a lane may keep 256 registers,
+// so KR = 5 K-steps of fragments (160 registers) live there, 2 more in LDS, and only ONE K-step (64 KB, 0.9 us)
+// is streamed per step - issued right after its use, it has the rest of the step and the next step's resident
+// MFMAs... to land.  To make room the accumulators start from the input projection (no separate copy of it is
+// alive during the MFMA phase) and the next step's projection is fetched only after the gates have retired them.
+template <int H, int KR>
+__global__ __launch_bounds__(512) void lstm_bidir_kernel4(const bf16_t* __restrict__ xproj, const bf16_t* __restrict__ wfrag,
+                                                          const int* __restrict__ lens,
+                                                          const long long* __restrict__ row_off,
+                                                          const int* __restrict__ tcap, const int* __restrict__ perm,
+                                                          bf16_t* __restrict__ y, int N, int T, int ndir) {
+  constexpr int G = 4 * H;
+  constexpr int NW = 8;
+  constexpr int TILES = G / 16 / NW;
+  constexpr int KS = H / 32;
+  constexpr int HROW = H * 2 + 16;
+  constexpr int KL = 2;                         // K-steps resident in LDS
+  constexpr int S0 = KR + KL;                   // first streamed K-step
+  constexpr int NS = KS - S0;                   // streamed K-steps (1 or 2), through ONE fragment buffer
+  static_assert(KS == 8 && TILES == 8, "H = 256");
+  static_assert(NS == 1 || NS == 2, "KR is 4 or 5");
+  extern __shared__ __attribute__((aligned(16))) char smem3[];
+  char* hb0 = smem3;
+  char* hb1 = smem3 + 16 * HROW;
+  char* wl = smem3 + 2 * 16 * HROW;             // [wave][KL][TILES][64 lanes] x 16 B
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int seq_l = lane & 15, fq = lane >> 4;
+  const int dir = blockIdx.y;
+  const long long xrow = (long long)ndir * G;
+  const long long yrow = (long long)ndir * H;
+
+  const int slot = blockIdx.x * 16 + seq_l;
+  const bool ok = slot < N;
+  const int n = ok ? (perm ? perm[slot] : slot) : 0;
+  const int cap = ok ? (tcap ? tcap[n] : T) : 0;
+  const int len = ok ? (lens ? min(lens[n], cap) : cap) : 0;
+  const long long row0 = ok ? (row_off ? row_off[n] : (long long)n * T) : 0;
+  const bf16_t* xp = xproj + row0 * xrow + (long long)dir * G + (wave * TILES) * 16 + fq * 4;
+  bf16_t* yp = y + row0 * yrow + (long long)dir * H;
+  int maxlen = len;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
+
+  for (int i = tid; i < 2 * 16 * HROW / 4; i += 512) reinterpret_cast<uint32_t*>(smem3)[i] = 0u;
+
+  const bf16_t* wf = wfrag + (long long)dir * G * H + (long long)wave * TILES * KS * 64 * 8 + lane * 8;
+  bf16x8 wr[KR][TILES];
+#pragma unroll
+  for (int k = 0; k < KR; ++k)
+#pragma unroll
+    for (int i = 0; i < TILES; ++i) wr[k][i] = *reinterpret_cast<const bf16x8*>(wf + (long long)(i * KS + k) * 64 * 8);
+  char* wlw = wl + ((wave * KL * TILES) * 64 + lane) * 16;
+#pragma unroll
+  for (int k = 0; k < KL; ++k)
+#pragma unroll
+    for (int i = 0; i < TILES; ++i)
+      *reinterpret_cast<bf16x8*>(wlw + (k * TILES + i) * 1024) =
+          *reinterpret_cast<const bf16x8*>(wf + (long long)(i * KS + KR + k) * 64 * 8);
+  __syncthreads();
+
+  float cst[TILES];
+#pragma unroll
+  for (int i = 0; i < TILES; ++i) cst[i] = 0.f;
+
+  bf16x8 ws[TILES];                             // the streamed K-step(s)
+#pragma unroll
+  for (int i = 0; i < TILES; ++i) ws[i] = *reinterpret_cast<const bf16x8*>(wf + (long long)(i * KS + S0) * 64 * 8);
+  u32x2 xc[TILES];
+  {
+    const int t0 = dir == 0 ? 0 : (len - 1);
+#pragma unroll
+    for (int i = 0; i < TILES; ++i) {
+      xc[i] = u32x2{0u, 0u};
+      if (len > 0) xc[i] = *reinterpret_cast<const u32x2*>(xp + (long long)t0 * xrow + i * 16);
+    }
+  }
+
+  for (int step = 0; step < maxlen; ++step) {
+    const char* hc = ((step & 1) ? hb1 : hb0) + seq_l * HROW + fq * 16;
+    char* hn = (step & 1) ? hb0 : hb1;
+    const bf16_t* wfs = wf;          // keep the streamed W loads inside the step loop
+    asm volatile("" : "+v"(wfs));
+    const bool act = step < len;
+    const int tt = dir == 0 ? step : (len - 1 - step);
+    // accumulators start from the input projection of this step (i, f, g, o pre-activations of the lane's unit)
+    f32x4 acc[TILES];
+#pragma unroll
+    for (int i = 0; i < TILES; ++i) {
+      const u32x2 raw = xc[i];
+      acc[i] = f32x4{bf16_bits_to_f32(raw[0] & 0xffffu), bf16_bits_to_f32(raw[0] >> 16), bf16_bits_to_f32(raw[1] & 0xffffu),
+                     bf16_bits_to_f32(raw[1] >> 16)};
+    }
+    // ---- streamed K-step S0 (arrived during the previous step)
+    {
+      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hc + S0 * 64);
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws[i], hf, acc[i], 0, 0, 0);
+      if (NS == 2) {
+#pragma unroll
+        for (int i = 0; i < TILES; ++i) ws[i] = *reinterpret_cast<const bf16x8*>(wfs + (long long)(i * KS + S0 + 1) * 64 * 8);
+      } else {
+#pragma unroll
+        for (int i = 0; i < TILES; ++i) ws[i] = *reinterpret_cast<const bf16x8*>(wfs + (long long)(i * KS + S0) * 64 * 8);
+      }
+    }
+    // ---- resident K-steps: registers
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hc + k * 64);
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[k][i], hf, acc[i], 0, 0, 0);
+    }
+    // ---- resident K-steps: LDS
+#pragma unroll
+    for (int k = 0; k < KL; ++k) {
+      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hc + (KR + k) * 64);
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) {
+        const bf16x8 w = *reinterpret_cast<const bf16x8*>(wlw + (k * TILES + i) * 1024);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, hf, acc[i], 0, 0, 0);
+      }
+    }
+    if (NS == 2) {
+      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hc + (S0 + 1) * 64);
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws[i], hf, acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) ws[i] = *reinterpret_cast<const bf16x8*>(wfs + (long long)(i * KS + S0) * 64 * 8);
+    }
+    // ---- gates
+    const char* hcr = ((step & 1) ? hb1 : hb0);
+#pragma unroll
+    for (int a = 0; a < TILES / 4; ++a) {
+      bf16x4 hv;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = a * 4 + q;
+        float ig = dl_sigmoid(acc[i][0]);
+        float fg = dl_sigmoid(acc[i][1]);
+        float gg = dl_tanh(acc[i][2]);
+        float og = dl_sigmoid(acc[i][3]);
+        float c = fg * cst[i] + ig * gg;
+        float h = og * dl_tanh(c);
+        if (act) cst[i] = c;
+        hv[q] = (bf16_t)h;
+      }
+      const int unit = (wave * (TILES / 4) + a) * 16 + fq * 4;
+      const int hoff = seq_l * HROW + unit * 2;
+      if (act) {
+        *reinterpret_cast<bf16x4*>(hn + hoff) = hv;
+        *reinterpret_cast<bf16x4*>(yp + (long long)tt * yrow + unit) = hv;
+      } else {
+        *reinterpret_cast<u32x2*>(hn + hoff) = *reinterpret_cast<const u32x2*>(hcr + hoff);
+      }
+    }
+    {
+      // next step's pre-activations (HBM): issued once the gates have retired the accumulators
+      const bool nact = step + 1 < len;
+      const int tn = dir == 0 ? step + 1 : (len - 2 - step);
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) {
+        xc[i] = u32x2{0u, 0u};
+        if (nact) xc[i] = *reinterpret_cast<const u32x2*>(xp + (long long)tn * xrow + i * 16);
+      }
+    }
+    __syncthreads();
+  }
+  if (ok) {
+    for (int t = len; t < cap; ++t)
+#pragma unroll
+      for (int a = 0; a < TILES / 4; ++a) {
+        const int unit = (wave * (TILES / 4) + a) * 16 + fq * 4;
+        *reinterpret_cast<u32x2*>(yp + (long long)t * yrow + unit) = u32x2{0u, 0u};
+      }
+  }
+}
+
+template <int KR>
+static int launch_lstm4(const void* xproj, const void* wfrag, const void* lens, const void* row_off, const void* tcap,
+                        const void* perm, void* y, int N, int T, int ndir, hipStream_t stream) {
+  constexpr int H = 256;
+  const size_t smem = 2 * 16 * (H * 2 + 16) + 8 * 2 * 8 * 1024;      // h double buffer + 128 KB of W_hh
+  auto k = lstm_bidir_kernel4<H, KR>;
+  static bool set = false;
+  if (!set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return -5;
+    set = true;
+  }
+  dim3 grid((N + 15) / 16, ndir);
+  hipLaunchKernelGGL(k, grid, dim3(512), smem, stream, (const bf16_t*)xproj, (const bf16_t*)wfrag, (const int*)lens,
+                     (const long long*)row_off, (const int*)tcap, (const int*)perm, (bf16_t*)y, N, T, ndir);
+  return DLAMD_CHECK_LAUNCH();
+}
+
 static int launch_lstm3(const void* xproj, const void* wfrag, const void* lens, const void* row_off, const void* tcap,
                         const void* perm, void* y, int N, int T, int ndir, hipStream_t stream) {
   constexpr int H = 256;
@@ -569,6 +767,8 @@ extern "C" int dlamd_lstm_bidir(const void* xproj, const void* wfrag, const void
   // v3 (half of W_hh resident in registers + LDS) beats both v2 shapes at every batch size measured:
   // N=1075: 4.94 us/step vs 7.23 (v2x16); N=4000: 10.0 vs 12.65 (v2x32)  [bench/lstm_bench.py]; small batches are
   // pure step latency, where v3 also wins (v1: ~10 us/step)
+  if (H == 256 && var == 5) return launch_lstm4<5>(xproj, wfrag, lens, row_off, tcap, perm, y, N, T, ndir, stream);
+  if (H == 256 && var == 6) return launch_lstm4<4>(xproj, wfrag, lens, row_off, tcap, perm, y, N, T, ndir, stream);
   if (H == 256 && (var == 4 || var == 0))
     return launch_lstm3(xproj, wfrag, lens, row_off, tcap, perm, y, N, T, ndir, stream);
   if (H == 256 && (var == 3 || (var == 0 && N >= 3072)))

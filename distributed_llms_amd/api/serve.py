@@ -79,13 +79,20 @@ def count_kfd_gpus(root: str = "/sys/class/kfd/kfd/topology/nodes") -> int:
 
 
 def child_main(fd: int) -> int:
-    import uvicorn
-
+    """One front end on the inherited listening socket.  ``OCR_HTTP_SERVER=uvicorn`` selects the stock server; the
+    default is the in-repo one (api/httpd.py: ~2x cheaper polls, body bytes received straight into the upload buffer)."""
     from ..config import Settings
     from .app import create_app
 
     app = create_app(Settings.from_env(dotenv=os.environ.get("OCR_DOTENV", ".env")))
-    uvicorn.run(app, fd=fd, log_level=os.environ.get("OCR_LOG_LEVEL", "warning"))
+    if os.environ.get("OCR_HTTP_SERVER", "dlamd").lower() == "uvicorn":
+        import uvicorn
+
+        uvicorn.run(app, fd=fd, log_level=os.environ.get("OCR_LOG_LEVEL", "warning"))
+    else:
+        from . import httpd
+
+        httpd.run(app, fd=fd)
     return 0
 
 
@@ -179,8 +186,11 @@ def main(argv=None) -> int:
     ap.add_argument("--frontends", type=int, default=0, help="0: one per 2 GPUs (at least 1)")
     ap.add_argument("--gpus", type=int, default=None, help="override the detected GPU count")
     ap.add_argument("--embedded-redis", action="store_true", help="force the embedded status store + file results")
+    ap.add_argument("--server", choices=["dlamd", "uvicorn"], default=os.environ.get("OCR_HTTP_SERVER", "dlamd"),
+                    help="HTTP server of every front end: the in-repo one (api/httpd.py) or uvicorn")
     ap.add_argument("--child-fd", type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
+    os.environ["OCR_HTTP_SERVER"] = args.server
     if args.child_fd >= 0:
         return child_main(args.child_fd)
     n = count_gpus() if args.gpus is None else args.gpus

@@ -127,6 +127,8 @@ class EngineConfig:
         bin_thresh=0.5, box_thresh=0.5, unclip_ratio=0.0, min_size=6, max_components=1024, max_boxes=32, max_angle_deg=0.0))
     fig_min_side_px: int = 90         # smaller regions are not figures (page pixels)
     max_figures_per_page: int = 8
+    fig_max_page_share: float = 0.4   # a "figure" that covers more of the page than this is a tinted page, not a figure
+    fig_max_lines: int = 8            # ... and one that holds this many text lines is a text region
 
 
 class StageTimer:
@@ -337,12 +339,18 @@ class OcrEngine:
                     area = (f[:, 2] - f[:, 0]) * (f[:, 3] - f[:, 1])
                     f = f[np.argsort(-area)[: cfg.max_figures_per_page]]
                 fg = f
+            if fg.shape[0]:
+                area = (fg[:, 2] - fg[:, 0]) * (fg[:, 3] - fg[:, 1])
+                fg = fg[area <= cfg.fig_max_page_share * float(p.hw[0]) * float(p.hw[1])]
             if r.shape[0] and fg.shape[0]:
-                # what the detector reads inside a figure (axis labels, legends) is part of the figure, not of the text
+                # what the detector reads inside a figure (axis labels, legends) is part of the figure, not of the
+                # text - unless it is a lot of text, in which case the region is no figure
                 cx, cy = 0.5 * (r[:, 0] + r[:, 2]), 0.5 * (r[:, 1] + r[:, 3])
                 inside = ((cx[:, None] >= fg[None, :, 0]) & (cx[:, None] <= fg[None, :, 2]) &
-                          (cy[:, None] >= fg[None, :, 1]) & (cy[:, None] <= fg[None, :, 3])).any(1)
-                r = r[~inside]
+                          (cy[:, None] >= fg[None, :, 1]) & (cy[:, None] <= fg[None, :, 3]))
+                real = inside.sum(0) < cfg.fig_max_lines
+                fg, inside = fg[real], inside[:, real]
+                r = r[~inside.any(1)]
             if r.shape[0] == 0 and fg.shape[0] == 0:
                 out.append((np.zeros((0, 7), np.float32), np.zeros((0, 5), np.float32)))
                 continue

@@ -41,6 +41,7 @@ class StatusStore:
     """Interface + shared JSON handling."""
 
     ttl: int = STATUS_TTL_SECONDS
+    in_process: bool = False      # True: lookups never block (no socket), callers may skip the I/O thread
 
     # -- primitives implemented by backends ------------------------------------
     def _setex(self, key: str, ttl: int, value: str) -> None:
@@ -185,6 +186,8 @@ class RedisStatusStore(StatusStore):
 
 class MemoryStatusStore(StatusStore):
     """In-process store with the same TTL semantics (``OCR_STORE=memory``, unit tests)."""
+
+    in_process = True
 
     def __init__(self, ttl: int = STATUS_TTL_SECONDS, clock: Callable[[], float] = time.monotonic):
         self.ttl, self.clock = ttl, clock
