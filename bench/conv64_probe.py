@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Probe: the Cout = 64 3x3 layers of the detector (layer1, FPN smooth convs, head) per kernel configuration."""
+import json
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch
+
+from distributed_llms_amd.ops import conv as C
+
+
+def timed(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def main():
+    dev = "cuda"
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 25
+    shapes = [("layer1 64->64 @1/4", 336, 240, 64, 64), ("head1 256->64 @1/4", 336, 240, 256, 64),
+              ("p3 256->64 @1/8", 168, 120, 256, 64), ("layer2 128->128 @1/8", 168, 120, 128, 128), ("layer3 256->256 @1/16", 84, 60, 256, 256),
+              ("crnn c3 128->256 12 rows", 12, 5000, 128, 256), ("crnn c2-like 64->128 s1 24 rows", 24, 5000, 64, 128)]
+    for name, H, W, Cin, Cout in shapes:
+        Bx = B if W < 1000 else 8
+        x = torch.randn(Bx, H, W, Cin, device=dev).to(torch.bfloat16)
+        w = (torch.randn(Cout, 3, 3, Cin, device=dev) * 0.02).to(torch.bfloat16)
+        b = torch.zeros(Cout, device=dev)
+        fl = 2.0 * (B if W < 1000 else 8) * H * W * Cout * 9 * Cin
+        row = {"layer": name, "gflop": round(fl / 1e9, 1)}
+        ref = None
+        for cfg in (0, 3064, 3264, 3464, 3428, 3128, 1128, 8256):
+            try:
+                y = C.conv2d_nhwc(x, w, b, stride=1, padding=1, act="relu", cfg=cfg)
+                if ref is None:
+                    ref = y.float()
+                else:
+                    assert (y.float() - ref).abs().max().item() < 0.1, cfg
+                ms = timed(lambda: C.conv2d_nhwc(x, w, b, stride=1, padding=1, act="relu", cfg=cfg))
+                row[str(cfg)] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1)}
+            except Exception as e:  # noqa: BLE001
+                row[str(cfg)] = str(e)[:60]
+        print(json.dumps(row), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -464,14 +464,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // Pixel (py, px) of the tile is fragment row lp = py*TW + px; with TW a multiple of 16 a wave's 16 fragment
 // rows are 16 consecutive x positions, so tap (dy, dx) is a constant offset in the patch.
 template <int TH, int TW, int SH, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv3x3_patch_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(const ConvArgs p) {
   constexpr int BM = TH * TW;
+  constexpr int NT = WM * WN * 64;                  // 4 waves on a 128-pixel tile, 8 waves on a 256-pixel tile
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int FM = TM / 16, FN = TN / 16;
   constexpr int PH = (TH - 1) * SH + 3, PW = TW + 2;
   constexpr int NCH = PH * PW * 8;                  // 16-byte chunks of one 64-channel patch
-  constexpr int PER = (NCH + 255) / 256;
-  static_assert(WM * WN == 4 && BM == 128 && TW % 16 == 0, "tile");
+  constexpr int PER = (NCH + NT - 1) / NT;
+  static_assert((WM * WN == 4 && BM == 128) || (WM * WN == 8 && BM == 256), "tile");
+  static_assert(TW % 16 == 0, "tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];   // PH*PW pixels x 128 B, XOR-swizzled chunks
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const ConvArgs p) {
   bool g_ok[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    const int e = tid + i * 256;
+    const int e = tid + i * NT;
     const int pp = e >> 3, c = e & 7;
     const int pr = pp / PW, pc = pp - pr * PW;
     const int y = iy0 + pr, x = ix0 + pc;
@@ -610,8 +612,27 @@ static int launch_patch(ConvArgs& a, hipStream_t stream) {
   if (smem > 65536 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
     return -2;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WM * WN * 64), smem, stream, a);
   return DLAMD_CHECK_LAUNCH();
+}
+
+// 256-pixel tiles (8 waves as 4 x 2): half the weight traffic per output pixel of the 128-pixel tile
+template <int SH, int BN>
+static int dispatch_patch256(ConvArgs& a, hipStream_t stream) {
+  int best = 16;
+  double bw = 1e9;
+  for (int th : {16, 8, 4, 2}) {
+    const int tw = 256 / th;
+    double w = (double)(((a.Ho + th - 1) / th) * th) / a.Ho * (double)(((a.Wo + tw - 1) / tw) * tw) / a.Wo *
+               (1.0 + 2.0 / (th * SH)) * (1.0 + 2.0 / tw);
+    if (w < bw - 1e-9) { bw = w; best = th; }
+  }
+  switch (best) {
+    case 16: return launch_patch<16, 16, SH, BN, 4, 2>(a, stream);
+    case 8: return launch_patch<8, 32, SH, BN, 4, 2>(a, stream);
+    case 4: return launch_patch<4, 64, SH, BN, 4, 2>(a, stream);
+    default: return launch_patch<2, 128, SH, BN, 4, 2>(a, stream);
+  }
 }
 
 // Tile-shape choice for the patch kernel: the tallest tile that wastes the fewest rows of Ho.
@@ -973,6 +994,21 @@ extern "C" int dlamd_conv2d(const void* x, const void* w, const float* bias, con
   // Measured (bench/kernel_bench.py --sweep, profiles/06_conv_tile_sweep.txt): the patch kernel wins by 1.3-1.5x when
   // Cout <= 64 (the im2col re-gather dominates: DBNet FPN smooth convs, head, layer1) and ties / loses against
   // the 64x128 direct-weight tile on wide layers, so auto mode uses it for narrow outputs only.
+  if (patch_ok && cfg == 3264)      // 64-channel tile as 2 x 2 waves: every wave streams half of the weights
+    return sh == 1 ? dispatch_patch<1, 64, 2, 2>(a, stream) : dispatch_patch<2, 64, 2, 2>(a, stream);
+  if (patch_ok && cfg == 3464)      // 256 pixels x 64 channels, 8 waves
+    return sh == 1 ? dispatch_patch256<1, 64>(a, stream) : dispatch_patch256<2, 64>(a, stream);
+  if (patch_ok && cfg == 3428)      // 256 pixels x 128 channels, 8 waves
+    return sh == 1 ? dispatch_patch256<1, 128>(a, stream) : dispatch_patch256<2, 128>(a, stream);
+  // Auto mode, stride 1 (bench/conv64_probe.py, 25 detector pages): the 64-channel tile as 2 x 2 waves, where every
+  // wave streams half of the weights from L2 instead of all of them, beats the 4 x 1 arrangement by 15-25 % on every
+  // Cout <= 64 layer (layer1 0.375 -> 0.290 ms, head 0.82 -> 0.68, FPN smooth 0.216 -> 0.182) and the 64 x 128
+  // direct-weight tile by 5-7 % on the 128-channel layers with shallow K; on the quarter-scale maps the 256-pixel
+  // 8-wave tile halves the weight traffic once more (layer1 0.270 ms, head 0.667).
+  if (patch_ok && cfg == 0 && sh == 1 && (Cout <= 64 || (Cout <= 128 && Cin <= 128))) {
+    if (Cout <= 64 && (long long)B * a.Ho * a.Wo >= 1000000 && a.Ho >= 16) return dispatch_patch256<1, 64>(a, stream);
+    return dispatch_patch<1, 64, 2, 2>(a, stream);
+  }
   if (patch_ok && ((cfg == 0 && Cout <= 64 && sh == 1) || cfg == 3064 || cfg == 3128)) {
     const bool wide = cfg == 3128 || (cfg == 0 && Cout > 64);
     if (sh == 1) return wide ? dispatch_patch<1, 128, 2, 2>(a, stream) : dispatch_patch<1, 64, 4, 1>(a, stream);

@@ -767,9 +767,12 @@ extern "C" int dlamd_lstm_bidir(const void* xproj, const void* wfrag, const void
   // v3 (half of W_hh resident in registers + LDS) beats both v2 shapes at every batch size measured:
   // N=1075: 4.94 us/step vs 7.23 (v2x16); N=4000: 10.0 vs 12.65 (v2x32)  [bench/lstm_bench.py]; small batches are
   // pure step latency, where v3 also wins (v1: ~10 us/step)
+  // v4 with 6 of 8 K-steps resident (4 in registers, 2 in LDS, 240 VGPRs, no spills): 3.74 us/step at N=1075 against
+  // 4.83 for v3; with 5 in registers the allocator spills four fragments and the reloads cost what the streaming saved
+  // (4.74 us/step), so auto picks KR = 4
   if (H == 256 && var == 5) return launch_lstm4<5>(xproj, wfrag, lens, row_off, tcap, perm, y, N, T, ndir, stream);
-  if (H == 256 && var == 6) return launch_lstm4<4>(xproj, wfrag, lens, row_off, tcap, perm, y, N, T, ndir, stream);
-  if (H == 256 && (var == 4 || var == 0))
+  if (H == 256 && (var == 6 || var == 0)) return launch_lstm4<4>(xproj, wfrag, lens, row_off, tcap, perm, y, N, T, ndir, stream);
+  if (H == 256 && var == 4)
     return launch_lstm3(xproj, wfrag, lens, row_off, tcap, perm, y, N, T, ndir, stream);
   if (H == 256 && (var == 3 || (var == 0 && N >= 3072)))
     return launch_lstm2<256, 2>(xproj, wfrag, lens, row_off, tcap, perm, y, N, T, ndir, stream);

@@ -46,6 +46,8 @@ class DocumentResult:
     text: str = ""
     timings: Dict[str, float] = field(default_factory=dict)
     error: Optional[str] = None                 # set instead of content when the document could not be read
+    language: str = "und"                       # utils/langid.detect over the combined text ("und": too little text)
+    language_confidence: float = 0.0
 
 
 _MD_HEADER = re.compile(r"#+\s+")
@@ -143,6 +145,9 @@ def assemble_document(document_id: str, mode: str, pages: Sequence[PageResult], 
     res.content_list = build_content_list(res.pages)
     res.markdown = "\n\n".join(("![](%s)" % it["img_path"]) if it["type"] == "image" else it["text"] for it in res.content_list)
     res.text = combine_text(res.content_list, res.markdown)
+    from ..utils.langid import detect
+
+    res.language, res.language_confidence = detect(res.text)
     if t0 is not None:
         res.timings = {"total_s": time.perf_counter() - t0}
     return res
