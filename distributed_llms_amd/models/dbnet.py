@@ -13,10 +13,12 @@ the MI355X inference path:
 * both 2x2/s2 transposed convs are GEMMs with a pixel-shuffle store; the last one
   applies sigmoid and emits the probability map and the >thr bitmask together;
 * a second, block-level head on the same 1/4-scale features (one 3x3 conv) marks
-  figure regions: the engine turns it into figure boxes with the same connected-
-  component kernels, keeps figures out of the text flow and hands their crops to
-  the image writer.  The reference gets its block layout from a separate YOLO
-  layout model (services/ocr_service/download_models_hf.py:38).
+  figure regions and display formulas: the engine turns both maps into boxes
+  with the same connected-component kernels, keeps figures out of the text flow
+  and hands their crops to the image writer, and sends formula crops to the
+  formula recogniser.  The reference gets its block layout from a separate YOLO
+  layout model and its formula boxes from another (services/ocr_service/
+  download_models_hf.py:38-39).
 
 In the reference the detector is the PaddleOCR-torch DB model downloaded by
 services/ocr_service/download_models_hf.py:41 and executed on CPU inside
@@ -61,7 +63,8 @@ class DBNet(nn.Module):
         self.head1 = ConvBNAct(inner, q, 3, 1, act="relu")
         self.head2 = Deconv2x2(q, q, act="relu", bn=True)
         self.head3 = Deconv2x2(q, 1, act="sigmoid", bn=False)
-        self.fig_head = ConvBNAct(q, 8, 3, 1, act="none", bn=False)     # channel 0: figure logit at 1/4 scale
+        # block head at 1/4 scale: channel 0 figure logit, channel 1 display-formula logit (6 spare channels)
+        self.fig_head = ConvBNAct(q, 8, 3, 1, act="none", bn=False)
         self.fuse_head_tail = True      # device inference: ops/conv.db_head_fused when q == 64
         self._head_tail = None
         self.inner, self.q = inner, q
@@ -79,7 +82,7 @@ class DBNet(nn.Module):
         return self.forward_all(x)[0]
 
     def forward_all(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        """-> (text probability [B,H,W], figure logit [B,H/4,W/4])."""
+        """-> (text probability [B,H,W], block logits [B,2,H/4,W/4]: channel 0 figure, channel 1 display formula)."""
         y = self.stem3(self.stem2(self.stem1(x)))
         feats = []
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
@@ -97,13 +100,13 @@ class DBNet(nn.Module):
         p2 = self.p2(o2)
         fuse = torch.cat([p5, p4, p3, p2], dim=1)
         h = self.head1(fuse)
-        return self.head3(self.head2(h))[:, 0], self.fig_head(h)[:, 0]
+        return self.head3(self.head2(h))[:, 0], self.fig_head(h)[:, :2]
 
     # ------------------------------------------------------------------ inference path (NHWC bf16)
     @torch.no_grad()
     def infer(self, x: torch.Tensor, concat_buf: Optional[torch.Tensor] = None, with_figures: bool = False):
         """x: [B,H,W,8] bf16 -> (prob [B,H,W] bf16, mask [B,H,W] u8); with_figures adds the block head's output
-        [B,H/4,W/4,8] bf16 (channel 0 = figure logit)."""
+        [B,H/4,W/4,8] bf16 (channel 0 = figure logit, channel 1 = formula logit)."""
         B, H, W, _ = x.shape
         assert H % 32 == 0 and W % 32 == 0, "detector input must be a multiple of 32"
         y = self.stem3.infer(self.stem2.infer(self.stem1.infer(x)))

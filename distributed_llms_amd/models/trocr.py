@@ -63,6 +63,17 @@ class TrOCRConfig:
         return (self.vocab + 15) // 16 * 16
 
 
+# Formula recogniser (the reference's MFR model, services/ocr_service/download_models_hf.py:40, is a UniMERNet
+# encoder-decoder): the same architecture at a size that trains in minutes.  Formula crops are letter-boxed into a
+# 96 x 384 canvas = 6 x 24 patches, the same 144 patch tokens as a 192 x 192 square.
+FORMULA_HW = (96, 384)
+
+
+def formula_config() -> TrOCRConfig:
+    return TrOCRConfig(image_size=192, enc_dim=256, enc_layers=4, enc_heads=4, enc_mlp=1024, dec_dim=256, dec_layers=4,
+                       dec_heads=4, dec_ffn=1024, vocab=272, max_len=128)
+
+
 class _EncLayer(nn.Module):
     def __init__(self, d: int, mlp: int):
         super().__init__()

@@ -76,6 +76,9 @@ class PageTruth:
     angle: float = 0.0           # degrees the finished page was turned counter-clockwise about its centre (skew)
     layout: str = "single"
     font_names: List[str] = field(default_factory=list)
+    formulas: np.ndarray = field(default_factory=lambda: np.zeros((0, 4), np.float32))  # display formulas, same frame
+    formula_texts: List[str] = field(default_factory=list)     # their LaTeX source
+    formula_pos: List[int] = field(default_factory=list)       # number of text lines that precede each formula
 
     def rotated_rects(self, size: Tuple[int, int]) -> np.ndarray:
         """Line boxes in the frame of the skewed image: [n, 5] cx, cy, w, h, angle (degrees, counter-clockwise)."""
@@ -209,17 +212,106 @@ def _figure_patch(rng: np.random.Generator, w: int, h: int) -> np.ndarray:
     return np.clip(g, 0, 255).astype(np.uint8)
 
 
+# --------------------------------------------------------------------------------------- formulas
+_F_VARS = list("abcdefghkmnpqrstuvwxyz") + list("ABCDEFGHKLMNPQRSTVXYZ")
+_F_GREEK = ["\\alpha", "\\beta", "\\gamma", "\\delta", "\\epsilon", "\\theta", "\\lambda", "\\mu", "\\pi", "\\rho",
+            "\\sigma", "\\phi", "\\omega", "\\Delta", "\\Omega", "\\Sigma"]
+_F_OPS = ["+", "-", "=", "\\cdot", "\\times", "\\leq", "\\geq", "\\neq", "\\approx", "\\pm", "<", ">", "\\to", "\\in"]
+_F_BIG = ["\\sum", "\\int", "\\prod"]
+_F_FUNCS = ["\\sin", "\\cos", "\\log", "\\exp", "\\max", "\\min", "\\lim"]
+
+
+def random_formula(rng: np.random.Generator, max_tokens: int = 14) -> str:
+    """A LaTeX formula (without the dollar signs) from a small grammar that matplotlib's mathtext renders: variables,
+    Greek letters, numbers, sub / superscripts, fractions, roots, big operators with limits, functions, relations.
+    Tokens are separated by single spaces, braces are minimal: the string is the recogniser's training target."""
+
+    def atom(depth: int) -> str:
+        r = rng.random()
+        if r < 0.40:
+            a = _F_VARS[int(rng.integers(len(_F_VARS)))]
+        elif r < 0.58:
+            a = _F_GREEK[int(rng.integers(len(_F_GREEK)))]
+        elif r < 0.72:
+            a = str(int(rng.integers(0, 100)))
+        elif r < 0.80 and depth < 2:
+            a = "\\frac{%s}{%s}" % (expr(depth + 1, 2), expr(depth + 1, 2))
+        elif r < 0.86 and depth < 2:
+            a = "\\sqrt{%s}" % expr(depth + 1, 2)
+        elif r < 0.92:
+            a = "%s(%s)" % (_F_FUNCS[int(rng.integers(len(_F_FUNCS)))], _F_VARS[int(rng.integers(len(_F_VARS)))])
+        elif depth < 2:
+            a = "(%s)" % expr(depth + 1, 3)
+        else:
+            a = _F_VARS[int(rng.integers(len(_F_VARS)))]
+        if a[0] not in "(\\" or a.startswith(("\\alpha", "\\beta", "\\gamma", "\\lambda", "\\sigma", "\\mu")):
+            q = rng.random()
+            if q < 0.22:
+                a += "_{%s}" % (_F_VARS[int(rng.integers(len(_F_VARS)))] if rng.random() < 0.6 else str(int(rng.integers(0, 10))))
+            if 0.15 < q < 0.35:
+                a += "^{%s}" % (str(int(rng.integers(2, 5))) if rng.random() < 0.7 else _F_VARS[int(rng.integers(len(_F_VARS)))])
+        return a
+
+    def expr(depth: int, n: int) -> str:
+        parts = [atom(depth)]
+        for _ in range(int(rng.integers(0, n))):
+            parts.append(_F_OPS[int(rng.integers(0, 5 if depth else len(_F_OPS)))])
+            parts.append(atom(depth))
+        return " ".join(parts)
+
+    n = int(rng.integers(2, max(3, max_tokens // 3)))
+    body = expr(0, n)
+    if rng.random() < 0.3:
+        big = _F_BIG[int(rng.integers(len(_F_BIG)))]
+        v = "ijkn"[int(rng.integers(4))]
+        body = "%s_{%s=%d}^{%s} %s" % (big, v, int(rng.integers(0, 2)), "nNmK"[int(rng.integers(4))], body)
+    if "=" not in body and rng.random() < 0.7:
+        body = "%s = %s" % (atom(1), body)
+    return body
+
+
+_MATH_PARSER = None
+_MATH_LOCK = None
+
+
+def render_formula(latex: str, px: int = 42, fontset: str = "cm") -> Optional[np.ndarray]:
+    """LaTeX -> uint8 [h, w] coverage (0 = paper, 255 = full ink), tightly cropped, through matplotlib's mathtext.
+    ``px`` is the height of an ordinary letter's em box in pixels.  None when mathtext cannot parse the string."""
+    global _MATH_PARSER, _MATH_LOCK
+    import threading
+
+    from matplotlib.font_manager import FontProperties
+    from matplotlib.mathtext import MathTextParser
+
+    if _MATH_LOCK is None:
+        _MATH_LOCK = threading.Lock()
+    with _MATH_LOCK:                       # the parser caches glyphs in shared state
+        if _MATH_PARSER is None:
+            _MATH_PARSER = MathTextParser("agg")
+        try:
+            r = _MATH_PARSER.parse("$" + latex + "$", dpi=72, prop=FontProperties(size=px, math_fontfamily=fontset))
+        except Exception:  # noqa: BLE001 - pyparsing errors of many kinds
+            return None
+        a = np.asarray(r.image, dtype=np.uint8).copy()
+    ys, xs = np.nonzero(a > 8)
+    if ys.size == 0:
+        return None
+    return a[ys.min() : ys.max() + 1, xs.min() : xs.max() + 1]
+
+
 LAYOUTS = ("single", "two_col", "two_col_title", "figure")
+FORMULA_FONTSETS = ("cm", "stix", "dejavusans", "dejavuserif", "stixsans")
 
 
 def render_layout_page(seed: int, size: Tuple[int, int] = A4_300DPI, layout: Optional[str] = None,
                        fonts: Optional[Sequence[str]] = None, font_px: Optional[int] = None, skew: float = 0.0,
                        noise: float = 2.0, blur: float = 0.0, margin: Optional[int] = None,
-                       header_footer: Optional[bool] = None) -> Tuple[np.ndarray, PageTruth]:
+                       header_footer: Optional[bool] = None, formulas: float = 0.0) -> Tuple[np.ndarray, PageTruth]:
     """A synthetic scanned page with a real layout: running header / footer, an optional full-width title, one or
     two columns of paragraphs, optionally a figure with its caption inside a column; one font per page drawn from
-    ``fonts``; optional skew (degrees), blur and sensor noise.  The truth lists the lines in READING order
-    (header, title, first column top to bottom, second column, footer) in the upright frame plus ``angle``."""
+    ``fonts``; optional skew (degrees), blur and sensor noise.  ``formulas`` > 0: that share of the paragraph breaks
+    carries a centred display formula (``random_formula`` through mathtext).  The truth lists the lines in READING
+    order (header, title, first column top to bottom, second column, footer) in the upright frame plus ``angle``."""
     W, H = size
     rng = np.random.default_rng(seed)
     layout = layout or LAYOUTS[int(rng.integers(len(LAYOUTS)))]
@@ -242,6 +334,8 @@ def render_layout_page(seed: int, size: Tuple[int, int] = A4_300DPI, layout: Opt
     line_h = int(px * rng.uniform(1.45, 1.7))
     ink = lambda: int(rng.integers(5, 80))
     boxes, texts, blocks, figures = [], [], [], []
+    fboxes, ftexts, fpos = [], [], []
+    fontset = FORMULA_FONTSETS[int(rng.integers(len(FORMULA_FONTSETS)))]
     block_id = [0]
 
     def put(x: int, y: int, t: str, ff, max_x: int) -> Optional[int]:
@@ -322,6 +416,19 @@ def render_layout_page(seed: int, size: Tuple[int, int] = A4_300DPI, layout: Opt
             if frac < 1.0 or rng.random() < 0.05:
                 yc += int(rng.uniform(0.9, 1.4) * line_h)       # paragraph gap
                 block_id[0] += 1
+                if formulas > 0 and rng.random() < formulas:
+                    latex = random_formula(rng)
+                    fm = render_formula(latex, int(px * rng.uniform(1.0, 1.25)), fontset)
+                    if fm is not None and 3 * px <= fm.shape[1] < col_w - 2 * px and yc + fm.shape[0] + 2 * line_h < bottom:
+                        fx = x0 + (col_w - fm.shape[1]) // 2
+                        cov = fm.astype(np.float32) / 255.0
+                        reg = np.asarray(img.crop((fx, yc, fx + fm.shape[1], yc + fm.shape[0])), dtype=np.float32)
+                        img.paste(Image.fromarray((reg * (1 - cov) + ink() * cov).astype(np.uint8)), (fx, yc))
+                        fboxes.append([fx - 4, yc - 4, fx + fm.shape[1] + 4, yc + fm.shape[0] + 4])
+                        ftexts.append(latex)
+                        fpos.append(len(texts))
+                        yc += fm.shape[0] + int(rng.uniform(0.9, 1.4) * line_h)
+                        block_id[0] += 1
         block_id[0] += 1
     if with_hf:
         t = f"{int(rng.integers(1, 400))}" if rng.random() < 0.5 else "Page %d of %d" % (int(rng.integers(1, 50)), 50)
@@ -338,7 +445,8 @@ def render_layout_page(seed: int, size: Tuple[int, int] = A4_300DPI, layout: Opt
         nz = np.repeat(np.repeat(nz, 4, axis=0), 4, axis=1)[:H, :W]
         arr = np.clip(arr.astype(np.float32) + nz, 0, 255).astype(np.uint8)
     truth = PageTruth(np.asarray(boxes, dtype=np.float32).reshape(-1, 4), texts,
-                      np.asarray(figures, dtype=np.float32).reshape(-1, 4), blocks, float(skew), layout, [fname])
+                      np.asarray(figures, dtype=np.float32).reshape(-1, 4), blocks, float(skew), layout, [fname],
+                      np.asarray(fboxes, dtype=np.float32).reshape(-1, 4), ftexts, fpos)
     return arr, truth
 
 

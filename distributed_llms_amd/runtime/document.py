@@ -92,29 +92,46 @@ def lines_to_paragraphs(lines: Sequence[TextLine]) -> List[str]:
     return [" ".join(p) for p in paras]
 
 
+def _line_items(lines: Sequence[TextLine], page_idx: int) -> List[dict]:
+    """Text paragraphs, with every display formula as an item of its own between them:
+    {'type': 'equation', 'text': '$$ ... $$', 'text_format': 'latex'} (magic-pdf's shape for interline equations; the
+    'text' key is what the combined text picks up, services/ocr_service/ocr_service.py:229-243)."""
+    items: List[dict] = []
+    run: List[TextLine] = []
+
+    def flush():
+        for para in lines_to_paragraphs(run):
+            items.append({"type": "text", "text": para, "page_idx": page_idx})
+        run.clear()
+
+    for ln in lines:
+        if getattr(ln, "kind", "text") == "equation":
+            flush()
+            items.append({"type": "equation", "text": ("$$ %s $$" % ln.text) if ln.text else "", "text_format": "latex",
+                          "page_idx": page_idx, "bbox": [round(float(v), 1) for v in ln.box]})
+        else:
+            run.append(ln)
+    flush()
+    return items
+
+
 def build_content_list(pages: Sequence[PageResult]) -> List[dict]:
-    """magic-pdf style content list: {'type': 'text', 'text', 'page_idx'} paragraphs and {'type': 'image',
-    'img_path', 'page_idx'} figures in reading order.  Only items with a 'text' key reach the combined text
-    (services/ocr_service/ocr_service.py:229-243)."""
+    """magic-pdf style content list: {'type': 'text', 'text', 'page_idx'} paragraphs, {'type': 'equation', ...}
+    display formulas and {'type': 'image', 'img_path', 'page_idx'} figures in reading order.  Only items with a 'text'
+    key reach the combined text (services/ocr_service/ocr_service.py:229-243)."""
     items = []
     for pg in pages:
         figs = sorted(pg.figures, key=lambda f: f.order)
-        if not figs:
-            for para in lines_to_paragraphs(pg.lines):
-                items.append({"type": "text", "text": para, "page_idx": pg.page_index})
-            continue
         # figures keep their place in the reading sequence: Figure.order counts lines + figures before it
         pos, li = 0, 0
         for fg in figs:
             take = max(0, fg.order - pos)
-            for para in lines_to_paragraphs(pg.lines[li : li + take]):
-                items.append({"type": "text", "text": para, "page_idx": pg.page_index})
+            items += _line_items(pg.lines[li : li + take], pg.page_index)
             li += take
             pos += take + 1
             items.append({"type": "image", "img_path": fg.path, "page_idx": pg.page_index,
                           "bbox": [round(float(v), 1) for v in fg.box]})
-        for para in lines_to_paragraphs(pg.lines[li:]):
-            items.append({"type": "text", "text": para, "page_idx": pg.page_index})
+        items += _line_items(pg.lines[li:], pg.page_index)
     return items
 
 

@@ -79,6 +79,7 @@ class TextLine:
     confidence: float
     block: int = 0               # text block (leaf region of the layout analysis); paragraphs never span blocks
     angle: float = 0.0           # radians the line is turned about the centre of ``box`` (skewed scans), 0 = upright
+    kind: str = "text"           # "equation": a display formula, ``text`` is its LaTeX source
 
 
 @dataclass
@@ -129,6 +130,13 @@ class EngineConfig:
     max_figures_per_page: int = 8
     fig_max_page_share: float = 0.4   # a "figure" that covers more of the page than this is a tinted page, not a figure
     fig_max_lines: int = 8            # ... and one that holds this many text lines is a text region
+    detect_formulas: bool = True      # second channel of the block head -> formula boxes -> formula recogniser
+    # a display formula is 60-100 page pixels tall = 6-10 pixels of the 1/4-scale block map: smaller size floor
+    frm_db: dbpost.DBPostConfig = field(default_factory=lambda: dbpost.DBPostConfig(
+        bin_thresh=0.5, box_thresh=0.5, unclip_ratio=0.0, min_size=2, max_components=1024, max_boxes=64, max_angle_deg=0.0))
+    formula_min_side_px: int = 16
+    formula_max_tokens: int = 96
+    max_formulas_per_page: int = 32
 
 
 class StageTimer:
@@ -147,11 +155,12 @@ class StageTimer:
 
 
 class _DetBatch:
-    __slots__ = ("pages", "srcs", "boxes_host", "nbox_host", "fig_host", "nfig_host", "event", "stream", "slot", "keep")
+    __slots__ = ("pages", "srcs", "boxes_host", "nbox_host", "fig_host", "nfig_host", "frm_host", "nfrm_host", "event", "stream",
+                 "slot", "keep")
 
 
 class _RecBatch:
-    __slots__ = ("det", "groups", "event", "results", "keep", "fig_crops")
+    __slots__ = ("det", "groups", "event", "results", "keep", "fig_crops", "formula_out")
 
 
 def deskewed_boxes(b4: np.ndarray, angles: np.ndarray, page_hw: Tuple[int, int]) -> Tuple[np.ndarray, float]:
@@ -174,7 +183,7 @@ def deskewed_boxes(b4: np.ndarray, angles: np.ndarray, page_hw: Tuple[int, int])
 
 class OcrEngine:
     def __init__(self, device: torch.device | str = "cuda:0", det: Optional[DBNet] = None, rec: Optional[CRNN] = None,
-                 cfg: Optional[EngineConfig] = None, seed: int = 0):   # rec: CRNN or TrOCR
+                 cfg: Optional[EngineConfig] = None, seed: int = 0, formula_rec=None):   # rec: CRNN or TrOCR
         self.device = torch.device(device)
         self.cfg = cfg or EngineConfig()
         self.on_gpu = self.device.type == "cuda"
@@ -189,6 +198,10 @@ class OcrEngine:
         # OCR_RECOGNIZER=trocr: ViT encoder + transformer decoder instead of the CRNN
         self.rec_kind = "crnn" if isinstance(rec, CRNN) else "trocr"
         self._trocr_event = None      # the decoder's static graph state is shared by both pipeline slots
+        self._formula_event = None
+        # formula recogniser (models/trocr.py at formula_config() size): without one, formula regions are reported
+        # as equations with empty LaTeX
+        self.formula_rec = formula_rec.to(self.device).prepare() if formula_rec is not None else None
         self.timer = StageTimer()
         self._ws: Dict[Tuple[int, int, int], dbpost.DBPostWorkspace] = {}
         ns = max(2, int(self.cfg.pipeline_slots))
@@ -248,11 +261,15 @@ class OcrEngine:
                 regions.append(rs.Region(img, (0.0, 0.0, float(img.shape[1]), float(img.shape[0])), oh, ow))
             x = self._resample(regions, Hd, Wd, rs.IMAGENET_MEAN, rs.IMAGENET_STD)
             figs = cfg.detect_figures and hasattr(self.det, "fig_head")
-            fprob = fmask = None
+            fprob = fmask = qprob = qmask = None
+            frm = figs and cfg.detect_formulas
             if figs:
                 prob, mask, fig = self.det.infer(x, with_figures=True)
                 fl = fig[..., 0].float()
                 fprob, fmask = torch.sigmoid(fl).to(torch.bfloat16).contiguous(), (fl > 0).to(torch.uint8).contiguous()
+                if frm:
+                    ql = fig[..., 1].float()
+                    qprob, qmask = torch.sigmoid(ql).to(torch.bfloat16).contiguous(), (ql > 0).to(torch.uint8).contiguous()
             else:
                 prob, mask = self.det.infer(x)
             scale = torch.tensor([[p.hw[1] / g[1], p.hw[0] / g[0]] for p, g in zip(pages, geo)],
@@ -271,7 +288,7 @@ class OcrEngine:
                 db.nbox_host = torch.empty((B,), dtype=torch.int32, pin_memory=True)
                 db.boxes_host.copy_(boxes[:B], non_blocking=True)
                 db.nbox_host.copy_(nbox[:B], non_blocking=True)
-                db.fig_host = db.nfig_host = None
+                db.fig_host = db.nfig_host = db.frm_host = db.nfrm_host = None
                 keep_f = None
                 if figs:
                     fkey = ("fig", slot, B, Hd // 4, Wd // 4)
@@ -287,15 +304,29 @@ class OcrEngine:
                     db.fig_host.copy_(fb[:B], non_blocking=True)
                     db.nfig_host.copy_(nf[:B], non_blocking=True)
                     keep_f = (fprob, fmask, fscale_d, fvalid_d)
+                    if frm:
+                        qkey = ("frm", slot, B, Hd // 4, Wd // 4)
+                        wq = self._ws.get(qkey)
+                        if wq is None:
+                            wq = dbpost.DBPostWorkspace(B, Hd // 4, Wd // 4, cfg.frm_db, self.device)
+                            self._ws[qkey] = wq
+                        qb, nq = dbpost.db_postprocess_gpu(qprob, qmask, wq, fscale_d, fvalid_d)
+                        db.frm_host = torch.empty(qb[:B].shape, dtype=qb.dtype, pin_memory=True)
+                        db.nfrm_host = torch.empty((B,), dtype=torch.int32, pin_memory=True)
+                        db.frm_host.copy_(qb[:B], non_blocking=True)
+                        db.nfrm_host.copy_(nq[:B], non_blocking=True)
+                        keep_f = keep_f + (qprob, qmask)
                 db.event = torch.cuda.Event()
                 db.event.record(st)
                 db.keep = (x, prob, mask, scale_d, valid_d, keep_f)
             else:
                 res = dbpost.db_postprocess_reference(prob, mask, cfg.db, scale, valid)
                 db.boxes_host, db.nbox_host, db.event = res, None, None
-                db.fig_host = db.nfig_host = None
+                db.fig_host = db.nfig_host = db.frm_host = db.nfrm_host = None
                 if figs:
                     db.fig_host = dbpost.db_postprocess_reference(fprob, fmask, cfg.fig_db, scale * 4.0, (valid + 3) // 4)
+                if frm:
+                    db.frm_host = dbpost.db_postprocess_reference(qprob, qmask, cfg.frm_db, scale * 4.0, (valid + 3) // 4)
                 db.keep = None
             db.srcs = srcs
         return db
@@ -310,10 +341,12 @@ class OcrEngine:
         return out
 
     def _det_boxes(self, db: _DetBatch) -> List[Tuple[np.ndarray, np.ndarray]]:
-        """Wait for the detector of this batch.  Per page: (lines [n, 7] = x0, y0, x1, y1, score, block, angle in
-        reading order, figures [m, 5] = x0, y0, x1, y1, position in the reading sequence)."""
+        """Wait for the detector of this batch.  Per page: (lines [n, 8] = x0, y0, x1, y1, score, block, angle, kind
+        (0 text line, 1 display formula) in reading order, figures [m, 5] = x0, y0, x1, y1, position in the reading
+        sequence)."""
         cfg = self.cfg
         nfig = None
+        frms = None
         if db.event is not None:
             db.event.synchronize()
             nb = db.nbox_host.numpy()
@@ -323,13 +356,32 @@ class OcrEngine:
             if db.fig_host is not None:
                 nfig, fx = db.nfig_host.numpy(), db.fig_host.numpy()
                 figs = [fx[b, : min(int(nfig[b]), cfg.fig_db.max_boxes), :4].copy() for b in range(len(db.pages))]
+            if db.frm_host is not None:
+                nq, qx = db.nfrm_host.numpy(), db.frm_host.numpy()
+                frms = [qx[b, : min(int(nq[b]), cfg.frm_db.max_boxes), :5].copy() for b in range(len(db.pages))]
         else:
             res = db.boxes_host
             figs = None if db.fig_host is None else [np.asarray(f, np.float32).reshape(-1, 8)[:, :4] for f in db.fig_host]
+            frms = None if db.frm_host is None else [np.asarray(f, np.float32).reshape(-1, 8)[:, :5] for f in db.frm_host]
         out = []
         for pi, (r, p) in enumerate(zip(res, db.pages)):
             r = np.asarray(r, dtype=np.float32)
             r = r.reshape(-1, r.shape[1] if r.ndim == 2 and r.shape[1] else 8)
+            if r.shape[1] < 8:
+                r = np.concatenate([r, np.zeros((r.shape[0], 8 - r.shape[1]), np.float32)], 1)
+            r[:, 7] = 0.0
+            if frms is not None and frms[pi].shape[0]:
+                q = frms[pi]
+                q = q[np.minimum(q[:, 2] - q[:, 0], q[:, 3] - q[:, 1]) >= cfg.formula_min_side_px][: cfg.max_formulas_per_page]
+                if q.shape[0]:
+                    # the text detector also fires on the pieces of a formula: what lies inside a formula box is dropped
+                    cx, cy = 0.5 * (r[:, 0] + r[:, 2]), 0.5 * (r[:, 1] + r[:, 3])
+                    inside = ((cx[:, None] >= q[None, :, 0]) & (cx[:, None] <= q[None, :, 2]) &
+                              (cy[:, None] >= q[None, :, 1]) & (cy[:, None] <= q[None, :, 3])).any(1)
+                    rows = np.zeros((q.shape[0], 8), np.float32)
+                    rows[:, :5] = q[:, :5]
+                    rows[:, 7] = 1.0
+                    r = np.concatenate([r[~inside], rows], 0)
             fg = np.zeros((0, 4), np.float32)
             if figs is not None and figs[pi].shape[0]:
                 f = figs[pi]
@@ -352,7 +404,7 @@ class OcrEngine:
                 fg, inside = fg[real], inside[:, real]
                 r = r[~inside.any(1)]
             if r.shape[0] == 0 and fg.shape[0] == 0:
-                out.append((np.zeros((0, 7), np.float32), np.zeros((0, 5), np.float32)))
+                out.append((np.zeros((0, 8), np.float32), np.zeros((0, 5), np.float32)))
                 continue
             # reading order by layout analysis (columns, headings, header / footer, figures as obstacles), in the
             # frame of the upright page when the scan is skewed
@@ -363,7 +415,8 @@ class OcrEngine:
             is_line = order < n
             lo = order[is_line]
             score = r[lo, 4:5] if r.shape[1] > 4 else np.ones((lo.size, 1), np.float32)
-            lines = np.concatenate([r[lo, :4], score, block[is_line][:, None].astype(np.float32), ang[lo][:, None]], 1)
+            lines = np.concatenate([r[lo, :4], score, block[is_line][:, None].astype(np.float32), ang[lo][:, None],
+                                    r[lo, 7:8]], 1)
             pos = np.nonzero(~is_line)[0]
             fo = np.concatenate([fg[order[pos] - n], pos[:, None].astype(np.float32)], 1) if pos.size else np.zeros((0, 5), np.float32)
             out.append((lines.astype(np.float32), fo.astype(np.float32)))
@@ -381,22 +434,26 @@ class OcrEngine:
             used_prior = False
             b5 = bx[:, [0, 1, 2, 3, 6]] if n_det else np.zeros((0, 5), np.float32)
             blk = bx[:, 5].astype(np.int32) if n_det else np.zeros((0,), np.int32)
+            knd = bx[:, 7].astype(np.int32) if n_det and bx.shape[1] > 7 else np.zeros((b5.shape[0],), np.int32)
             if p.layout_prior is not None and not self._detections_usable(bx, p):
                 b4 = np.asarray(p.layout_prior, dtype=np.float32).reshape(-1, 4)
                 order, blk, _ = layout.order_page_native(b4, float(p.hw[0]))
                 b5 = np.concatenate([b4[order], np.zeros((b4.shape[0], 1), np.float32)], 1)
+                knd = np.zeros((b5.shape[0],), np.int32)
                 used_prior = True
                 fg = fg[:0]
             b5 = b5[: cfg.max_lines_per_page]
             blk = blk[: cfg.max_lines_per_page]
-            per_page.append((n_det, used_prior, b5, blk, fg))
+            knd = knd[: cfg.max_lines_per_page]
+            per_page.append((n_det, used_prior, b5, blk, fg, knd))
             all_boxes.append(b5)
             all_page.append(np.full((b5.shape[0],), pi, dtype=np.int32))
         boxes = np.concatenate(all_boxes, 0) if all_boxes else np.zeros((0, 5), np.float32)
         page_of = np.concatenate(all_page, 0) if all_page else np.zeros((0,), np.int32)
+        kind = np.concatenate([pp[5] for pp in per_page], 0) if per_page else np.zeros((0,), np.int32)
         w = boxes[:, 2] - boxes[:, 0]
         h = boxes[:, 3] - boxes[:, 1]
-        ok = (w >= cfg.min_line_px) & (h >= cfg.min_line_px)
+        ok = (w >= cfg.min_line_px) & (h >= cfg.min_line_px) & (kind == 0)
         rot = (h > cfg.vertical_ratio * w).astype(np.int32)
         long_side = np.where(rot == 1, h, w)
         short_side = np.maximum(np.where(rot == 1, w, h), 1.0)
@@ -423,10 +480,11 @@ class OcrEngine:
         rb.groups = []
         rb.keep = []
         rb.fig_crops = self._fetch_figures(db, per_page)
+        rb.formula_out = self._submit_formulas(db, per_page, boxes, page_of)
         idx_all = np.nonzero(ok)[0]
         if idx_all.size == 0:
             rb.event = None
-            if rb.fig_crops and self.on_gpu:
+            if (rb.fig_crops or rb.formula_out is not None) and self.on_gpu:
                 rb.event = torch.cuda.Event()
                 rb.event.record(db.stream)
             return rb
@@ -511,12 +569,61 @@ class OcrEngine:
         else:
             rb.event = None
 
+    def _submit_formulas(self, db: _DetBatch, per_page, boxes: np.ndarray, page_of: np.ndarray):
+        """Formula boxes of the batch -> letter-boxed 96 x 384 crops -> encoder-decoder -> LaTeX token ids (started
+        here, read in ``_finish``).  Returns (global line indices, tokens, confidences) or None."""
+        kind = np.concatenate([pp[5] for pp in per_page], 0) if per_page else np.zeros((0,), np.int32)
+        idx = np.nonzero(kind == 1)[0]
+        if idx.size == 0 or self.formula_rec is None:
+            return None
+        from ..models.trocr import FORMULA_HW
+
+        cfg = self.cfg
+        H, W = FORMULA_HW
+        w = np.maximum(boxes[idx, 2] - boxes[idx, 0], 1.0)
+        h = np.maximum(boxes[idx, 3] - boxes[idx, 1], 1.0)
+        sc = np.minimum(W / w, H / h)
+        ow = np.clip(np.rint(w * sc), 1, W).astype(np.int32)
+        oh = np.clip(np.rint(h * sc), 1, H).astype(np.int32)
+        ctx = torch.cuda.stream(db.stream) if self.on_gpu else _null_ctx()
+        with ctx:
+            if self.on_gpu:
+                if self._formula_event is not None:
+                    db.stream.wait_event(self._formula_event)     # one decode state: formula passes run in order
+                ptrs = np.array([s_.data_ptr() for s_ in db.srcs], dtype=np.uint64)
+                Hs = np.array([s_.shape[0] for s_ in db.srcs], dtype=np.int32)
+                Ws = np.array([s_.shape[1] for s_ in db.srcs], dtype=np.int32)
+                Cs = np.array([1 if s_.dim() == 2 else s_.shape[2] for s_ in db.srcs], dtype=np.int32)
+                Ps = np.array([s_.stride(0) for s_ in db.srcs], dtype=np.int32)
+                out_w_all = np.zeros((boxes.shape[0],), np.int32)
+                out_w_all[idx] = ow
+                items = self._crop_items(idx, boxes, page_of, np.zeros((boxes.shape[0],), np.int32), out_w_all,
+                                         (ptrs, Hs, Ws, Cs, Ps))
+                items["out_h"] = oh
+                host = torch.from_numpy(items.view(np.uint8).reshape(-1)).pin_memory()
+                dev = host.to(self.device, non_blocking=True)
+                x = rs.resample_items_gpu(dev, idx.size, H, W, rs.HALF_MEAN, rs.HALF_STD)
+                toks, conf = self.formula_rec.generate(x, max_len=cfg.formula_max_tokens, use_graph=cfg.use_hip_graphs,
+                                                       eos_check_every=0)
+                h_tok = torch.empty(toks.shape, dtype=torch.int32, pin_memory=True)
+                h_cf = torch.empty(conf.shape, dtype=torch.float32, pin_memory=True)
+                h_tok.copy_(toks, non_blocking=True)
+                h_cf.copy_(conf, non_blocking=True)
+                self._formula_event = torch.cuda.Event()
+                self._formula_event.record(db.stream)
+                return idx, h_tok, h_cf, (host, dev, x)
+            regions = [rs.Region(db.srcs[page_of[i]], tuple(float(v) for v in boxes[i, :4]), int(oh[k]), int(ow[k]))
+                       for k, i in enumerate(idx)]
+            x = rs.resample_regions(regions, H, W, rs.HALF_MEAN, rs.HALF_STD)
+            toks, conf = self.formula_rec.generate(x, max_len=cfg.formula_max_tokens, use_graph=False, eos_check_every=8)
+            return idx, toks.to(torch.int32), conf.float(), None
+
     def _fetch_figures(self, db: _DetBatch, per_page) -> Dict[Tuple[int, int], torch.Tensor]:
         """Start the device-to-host copies of the figure crops of this batch (page raster pixels, full resolution)."""
         crops: Dict[Tuple[int, int], torch.Tensor] = {}
         ctx = torch.cuda.stream(db.stream) if self.on_gpu else _null_ctx()
         with ctx:
-            for pi, (_, _, _, _, fg) in enumerate(per_page):
+            for pi, (_, _, _, _, fg, _) in enumerate(per_page):
                 src = db.srcs[pi]
                 Hs, Ws = int(src.shape[0]), int(src.shape[1])
                 for k in range(fg.shape[0]):
@@ -632,14 +739,23 @@ class OcrEngine:
             for j, gi in enumerate(ids):
                 texts[gi] = strs[j]
             confs[ids] = cf
+        if rb.formula_out is not None:
+            fidx, h_tok, h_cf = rb.formula_out[:3]
+            strs = self.formula_rec.tokens_to_text(h_tok[: len(fidx)])
+            for j, gi in enumerate(fidx):
+                texts[gi] = strs[j].strip()
+            confs[fidx] = h_cf[: len(fidx)].numpy()
         results = []
         pos = 0
-        for pi, (p, (n_det, used_prior, b4, blk, fg)) in enumerate(zip(rb.det.pages, per_page)):
+        for pi, (p, (n_det, used_prior, b4, blk, fg, knd)) in enumerate(zip(rb.det.pages, per_page)):
             r = PageResult(p.doc_id, p.page_index, p.hw[1], p.hw[0],
                            n_detected=n_det, used_layout_prior=used_prior)
             for k in range(b4.shape[0]):
                 gi = pos + k
-                if ok[gi]:
+                if knd[k] == 1:
+                    r.lines.append(TextLine(tuple(float(v) for v in b4[k, :4]), texts[gi], float(confs[gi]), int(blk[k]),
+                                            0.0, "equation"))
+                elif ok[gi]:
                     r.lines.append(TextLine(tuple(float(v) for v in b4[k, :4]), texts[gi], float(confs[gi]), int(blk[k]),
                                             float(b4[k, 4])))
             for k in range(fg.shape[0]):

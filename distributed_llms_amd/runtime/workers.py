@@ -77,7 +77,15 @@ def build_engine(device: str, engine_spec: Dict) -> "object":
         rec_file = os.path.join(wd, "trocr.safetensors" if kind == "trocr" else "crnn.safetensors")
         if kind != "trocr" or os.path.exists(rec_file):
             load_model_weights(rec, rec_file, strict=False)
-    return OcrEngine(device, det, rec, cfg)
+    formula = None
+    fpath = os.path.join(wd, "formula.safetensors") if wd and str(wd).lower() != "none" else None
+    if fpath and os.path.exists(fpath) and engine_spec.get("model", "full") == "full":
+        from ..models.trocr import TrOCR, formula_config
+        from ..utils.weights import load_model_weights
+
+        formula = TrOCR(formula_config())
+        load_model_weights(formula, fpath)
+    return OcrEngine(device, det, rec, cfg, formula_rec=formula)
 
 
 def worker_main(worker_id: int, device: str, engine_spec: Dict, task_q, result_q, fault_spec: str = "",

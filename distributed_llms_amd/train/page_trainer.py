@@ -58,7 +58,7 @@ def augment_scan(pg: np.ndarray, rng: np.random.Generator) -> np.ndarray:
     return np.ascontiguousarray(out)
 
 
-def render_training_page(seed: int, fonts=None, plain_share: float = 0.2, max_skew: float = 5.0):
+def render_training_page(seed: int, fonts=None, plain_share: float = 0.2, max_skew: float = 5.0, formula_share: float = 0.4):
     """One page of the training distribution (see the module docstring) and its truth."""
     rng = np.random.default_rng(seed)
     if rng.random() < plain_share:
@@ -67,7 +67,8 @@ def render_training_page(seed: int, fonts=None, plain_share: float = 0.2, max_sk
     skew = float(rng.uniform(-max_skew, max_skew)) if rng.random() < 0.7 else 0.0
     blur = float(rng.uniform(0.3, 1.1)) if rng.random() < 0.4 else 0.0
     pg, truth = synth.render_layout_page(seed, fonts=fonts or synth.TRAIN_FONTS, skew=skew, blur=blur,
-                                         noise=float(rng.uniform(0.5, 5.0)))
+                                         noise=float(rng.uniform(0.5, 5.0)),
+                                         formulas=float(rng.uniform(0.3, 0.9)) if rng.random() < formula_share else 0.0)
     return augment_scan(pg, rng), truth
 
 
@@ -154,7 +155,7 @@ def _raster_polys(polys: np.ndarray, W: int, H: int) -> np.ndarray:
 
 def det_targets(truth: synth.PageTruth, hw: Tuple[int, int], scale: float, Hd: int, Wd: int,
                 unclip_ratio: float = 1.5) -> Tuple[np.ndarray, np.ndarray]:
-    """-> (text kernel mask [Hd, Wd], figure mask [Hd/4, Wd/4]) at detector scale."""
+    """-> (text kernel mask [Hd, Wd], block masks [2, Hd/4, Wd/4]: figures, display formulas) at detector scale."""
     r = line_rects(truth, hw)
     if r.shape[0]:
         up = np.stack([-0.5 * r[:, 2], -0.5 * r[:, 3], 0.5 * r[:, 2], 0.5 * r[:, 3]], 1)
@@ -163,17 +164,18 @@ def det_targets(truth: synth.PageTruth, hw: Tuple[int, int], scale: float, Hd: i
         r[:, 2], r[:, 3] = sh[:, 2] - sh[:, 0], sh[:, 3] - sh[:, 1]
         r[:, :4] *= scale
     text = _raster_polys(rect_corners(r), Wd, Hd) if r.shape[0] else np.zeros((Hd, Wd), np.uint8)
-    fig = np.zeros((Hd // 4, Wd // 4), np.uint8)
-    if truth.figures.shape[0]:
-        f = synth.rotate_boxes(truth.figures, truth.angle, (hw[1], hw[0])).astype(np.float64)
-        f[:, 4] = -np.deg2rad(f[:, 4])
-        f[:, :4] *= scale / 4.0
-        fig = _raster_polys(rect_corners(f), Wd // 4, Hd // 4)
+    fig = np.zeros((2, Hd // 4, Wd // 4), np.uint8)
+    for k, bx in enumerate((truth.figures, truth.formulas)):
+        if bx.shape[0]:
+            f = synth.rotate_boxes(bx, truth.angle, (hw[1], hw[0])).astype(np.float64)
+            f[:, 4] = -np.deg2rad(f[:, 4])
+            f[:, :4] *= scale / 4.0
+            fig[k] = _raster_polys(rect_corners(f), Wd // 4, Hd // 4)
     return text, fig
 
 
 def det_batch(pages, device, Hd=1344, Wd=960, crop=(640, 640), per_page=2):
-    """-> x [N,3,h,w] f32 normalised (detector scale), text target [N,h,w], figure target [N,h/4,w/4]."""
+    """-> x [N,3,h,w] f32 normalised (detector scale), text target [N,h,w], block targets [N,2,h/4,w/4]."""
     xs, ts, fs = [], [], []
     for img, truth in pages:
         H, W = img.shape
@@ -188,7 +190,7 @@ def det_batch(pages, device, Hd=1344, Wd=960, crop=(640, 640), per_page=2):
             cx = 32 * np.random.randint(0, (Wd - crop[1]) // 32 + 1)
             xs.append(x[:, cy:cy + crop[0], cx:cx + crop[1]])
             ts.append(t[cy:cy + crop[0], cx:cx + crop[1]])
-            fs.append(f[cy // 4:(cy + crop[0]) // 4, cx // 4:(cx + crop[1]) // 4])
+            fs.append(f[:, cy // 4:(cy + crop[0]) // 4, cx // 4:(cx + crop[1]) // 4])
     return torch.stack(xs), torch.stack(ts), torch.stack(fs)
 
 
@@ -205,14 +207,16 @@ def det_loss(prob: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
 
 
 def fig_loss(logit: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
-    """Block head: balanced BCE on logits + dice on the sigmoid."""
-    logit = logit.float()
-    pos = target > 0.5
-    bce = F.binary_cross_entropy_with_logits(logit, target, reduction="none")
-    l_bce = bce[pos].sum() / pos.sum().clamp(min=1) + bce[~pos].sum() / (~pos).sum().clamp(min=1)
-    p = torch.sigmoid(logit)
-    dice = 1 - (2 * (p * target).sum() + 1.0) / (p.sum() + target.sum() + 1.0)
-    return l_bce + dice
+    """Block head: balanced BCE on logits + dice on the sigmoid, per channel (figures, formulas)."""
+    total = logit.new_zeros((), dtype=torch.float32)
+    for c in range(logit.shape[1]):
+        lg, tg = logit[:, c].float(), target[:, c]
+        pos = tg > 0.5
+        bce = F.binary_cross_entropy_with_logits(lg, tg, reduction="none")
+        l_bce = bce[pos].sum() / pos.sum().clamp(min=1) + bce[~pos].sum() / (~pos).sum().clamp(min=1)
+        p = torch.sigmoid(lg)
+        total = total + l_bce + 1 - (2 * (p * tg).sum() + 1.0) / (p.sum() + tg.sum() + 1.0)
+    return total
 
 
 REC_BUCKETS = (1280, 2048)      # static training shapes: every new conv shape costs MIOpen a kernel build

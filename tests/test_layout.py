@@ -3,6 +3,7 @@ footers, figures, label-value rows; native implementation against the Python ora
 of the document pipeline on a two-column PDF whose content stream interleaves the columns."""
 import numpy as np
 import pytest
+import torch
 
 from distributed_llms_amd.pdf import reader, synth
 from distributed_llms_amd.runtime import layout
@@ -91,3 +92,73 @@ def test_txt_branch_of_the_pipeline_uses_layout_order():
     assert text.startswith("Two Columns")
     # the title, the left column and the right column are separate paragraphs
     assert len(doc.content_list) >= 3
+
+
+class _PaintedDetector(torch.nn.Module):
+    """Stands in for the trained detector on CPU: paints the maps a perfect detector would emit from the page truth
+    (text kernels, figure mask, formula mask), so the engine's box / ordering / crop / recognition plumbing runs."""
+
+    def __init__(self, truth, page_hw):
+        super().__init__()
+        self.truth, self.page_hw = truth, page_hw
+        self.fig_head = torch.nn.Identity()
+        self.dummy = torch.nn.Parameter(torch.zeros(1))
+
+    def prepare(self):
+        return self
+
+    def infer(self, x, concat_buf=None, with_figures=False):
+        from distributed_llms_amd.train.page_trainer import shrink_boxes
+
+        B, H, W, _ = x.shape
+        sc = H / self.page_hw[0]
+        prob = torch.zeros((B, H, W))
+        for b in shrink_boxes(self.truth.boxes) * sc:
+            x0, y0, x1, y1 = [int(round(float(v))) for v in b]
+            prob[:, y0:max(y1, y0 + 1), x0:max(x1, x0 + 1)] = 0.9
+        for b in self.truth.formulas * sc:            # a real text head also fires on formula pieces
+            x0, y0, x1, y1 = [int(round(float(v))) for v in b]
+            prob[:, (y0 + y1) // 2 - 2:(y0 + y1) // 2 + 2, x0 + 4:x1 - 4] = 0.9
+        fig = torch.full((B, H // 4, W // 4, 8), -6.0)
+        for k, boxes in enumerate((self.truth.figures, self.truth.formulas)):
+            for b in boxes * sc / 4:
+                x0, y0, x1, y1 = [int(round(float(v))) for v in b]
+                fig[:, y0:y1, x0:x1, k] = 6.0
+        out = (prob.to(torch.bfloat16), (prob > 0.3).to(torch.uint8))
+        return out + (fig.to(torch.bfloat16),) if with_figures else out
+
+
+def test_formulas_become_equation_items_in_reading_order():
+    from distributed_llms_amd.models.crnn import CRNN
+    from distributed_llms_amd.models.trocr import TrOCR, TrOCRConfig
+    from distributed_llms_amd.runtime.document import build_content_list
+    from distributed_llms_amd.runtime.engine import EngineConfig, OcrEngine, PageImage
+
+    pg, tr = synth.render_layout_page(11, size=(1240, 1754), layout="single", formulas=0.9, noise=1.0)
+    assert tr.formulas.shape[0] >= 2
+    torch.manual_seed(0)
+    frm = TrOCR(TrOCRConfig(image_size=192, enc_dim=64, enc_layers=1, enc_heads=1, enc_mlp=128, dec_dim=64, dec_layers=1,
+                            dec_heads=1, dec_ffn=128, vocab=272, max_len=24))
+    eng = OcrEngine("cpu", _PaintedDetector(tr, pg.shape), CRNN(hidden=64, widths=(16, 32, 32, 32, 64, 64)),
+                    EngineConfig(det_limit_side=1344, max_batch_pages=1, formula_max_tokens=12, formula_min_side_px=6), formula_rec=frm)
+    res = eng.process_pages([PageImage(torch.from_numpy(pg.copy()), "f", 0)])[0]
+    kinds = [l.kind for l in res.lines]
+    assert kinds.count("equation") == tr.formulas.shape[0] and kinds.count("text") == len(tr.texts)
+    # every formula sits where the truth has it: after `formula_pos` text lines
+    seen_text = 0
+    got_pos = []
+    for l in res.lines:
+        if l.kind == "equation":
+            got_pos.append(seen_text)
+        else:
+            seen_text += 1
+    assert got_pos == tr.formula_pos
+    for l, t in zip([l for l in res.lines if l.kind == "equation"], tr.formulas):
+        ix = max(0.0, min(l.box[2], t[2]) - max(l.box[0], t[0])) * max(0.0, min(l.box[3], t[3]) - max(l.box[1], t[1]))
+        assert ix / ((t[2] - t[0]) * (t[3] - t[1])) > 0.7
+    items = build_content_list([res])
+    eq = [it for it in items if it["type"] == "equation"]
+    assert len(eq) == tr.formulas.shape[0] and all(it["text_format"] == "latex" and "bbox" in it for it in eq)
+    # equations split the text flow: no paragraph spans a formula
+    order = [it["type"] for it in items]
+    assert order[0] == "text" and "equation" in order[1:-1]
