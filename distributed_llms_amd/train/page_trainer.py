@@ -299,8 +299,28 @@ def evaluate_pages(engine, pages_truth, verbose=False):
     res = engine.process_pages(pages)
     n_truth = n_found = ed = nchar = ed_page = 0
     fig_truth = fig_found = 0
+    frm_truth = frm_found = frm_ed = frm_ch = frm_false = 0
     for r, (pg, tr) in zip(res, pages_truth):
         rects = line_rects(tr, pg.shape)
+        eqs = [l for l in r.lines if getattr(l, "kind", "text") == "equation"]
+        r.lines = [l for l in r.lines if getattr(l, "kind", "text") != "equation"]
+        frects = synth.rotate_boxes(tr.formulas, tr.angle, (pg.shape[1], pg.shape[0])) if tr.formulas.shape[0] else np.zeros((0, 5))
+        hit = set()
+        for fr, latex in zip(frects, tr.formula_texts):
+            frm_truth += 1
+            frm_ch += len(latex)
+            best, bk = 1e9, -1
+            for k, l in enumerate(eqs):
+                dd = np.hypot(0.5 * (l.box[0] + l.box[2]) - fr[0], 0.5 * (l.box[1] + l.box[3]) - fr[1])
+                if dd < best:
+                    best, bk = dd, k
+            if bk >= 0 and bk not in hit and best <= 0.5 * fr[3] + 0.1 * fr[2]:
+                hit.add(bk)
+                frm_found += 1
+                frm_ed += min(len(latex), _edit_distance(eqs[bk].text, latex))
+            else:
+                frm_ed += len(latex)
+        frm_false += len(eqs) - len(hit)
         lc = np.array([[0.5 * (l.box[0] + l.box[2]), 0.5 * (l.box[1] + l.box[3])] for l in r.lines], np.float64).reshape(-1, 2)
         used = set()
         for rc, t in zip(rects, tr.texts):
@@ -326,7 +346,9 @@ def evaluate_pages(engine, pages_truth, verbose=False):
     return {"det_recall": n_found / max(n_truth, 1), "cer": ed / max(nchar, 1), "page_cer": ed_page / max(nchar, 1),
             "boxes_per_page": float(np.mean([len(r.lines) for r in res])),
             "truth_per_page": float(np.mean([len(t.texts) for _, t in pages_truth])),
-            "figures_found": fig_found, "figures_truth": fig_truth}
+            "figures_found": fig_found, "figures_truth": fig_truth,
+            "formulas_found": frm_found, "formulas_truth": frm_truth, "formulas_false": frm_false,
+            "formula_cer": frm_ed / max(frm_ch, 1)}
 
 
 def held_out_pages(seeds, skew=3.0, fonts=None):
@@ -339,16 +361,26 @@ def held_out_pages(seeds, skew=3.0, fonts=None):
     return out
 
 
-def evaluate(det, rec, device, seeds, verbose=False):
+def evaluate(det, rec, device, seeds, verbose=False, formula_weights=None):
     """Three held-out sets: the benchmark's page family (unseen seeds), layout pages in the training fonts, layout
     pages in held-out fonts at +-3 degrees of skew."""
     from ..runtime.engine import EngineConfig, OcrEngine
 
-    eng = OcrEngine(device, det, rec, EngineConfig(max_batch_pages=4))
+    formula = None
+    if formula_weights and os.path.exists(formula_weights):
+        from ..models.trocr import TrOCR, formula_config
+        from ..utils.weights import load_model_weights
+
+        formula = TrOCR(formula_config())
+        load_model_weights(formula, formula_weights)
+    eng = OcrEngine(device, det, rec, EngineConfig(max_batch_pages=4), formula_rec=formula)
     out = {}
     out["plain"] = evaluate_pages(eng, [synth.render_page(sd) for sd in seeds[:4]], verbose)
     out["layout_train_fonts"] = evaluate_pages(eng, [render_training_page(sd, plain_share=0.0) for sd in seeds], verbose)
     out["held_out_fonts_skew3"] = evaluate_pages(eng, held_out_pages(seeds), verbose)
+    out["formula_pages"] = evaluate_pages(eng, [synth.render_layout_page(sd, fonts=synth.TRAIN_FONTS, formulas=0.8,
+                                                                         layout=synth.LAYOUTS[k % 3])
+                                                for k, sd in enumerate(seeds[:4])], verbose)
     det.train()
     rec.train()
     return out
@@ -361,7 +393,8 @@ def write_meta(out_dir: str, steps: int, ev, log) -> None:
                "held_out_fonts": synth.available_fonts(synth.HELD_OUT_FONTS),
                "augmentation": {"skew_deg": 5.0, "blur_sigma": [0.3, 1.1], "noise_sigma": [0.5, 5.0],
                                 "contrast": [0.7, 1.15], "jpeg_quality": [35, 95], "font_px": [30, 50],
-                                "layouts": list(synth.LAYOUTS) + ["plain"]}},
+                                "layouts": list(synth.LAYOUTS) + ["plain"],
+                                "display_formulas": "40 % of the layout pages carry formulas (synth.random_formula, mathtext)"}},
               open(os.path.join(out_dir, "train_meta.json"), "w"), indent=1)
 
 
@@ -383,6 +416,7 @@ def main(argv=None) -> int:
     det, rec = DBNet().to(device), CRNN().to(device)
     os.makedirs(args.out, exist_ok=True)
     dp, rp = os.path.join(args.out, "dbnet.safetensors"), os.path.join(args.out, "crnn.safetensors")
+    fw = os.path.join(args.out, "formula.safetensors")      # used by the evaluation when present
     start = 0
     if args.init and not (args.resume and os.path.exists(dp)):
         from ..utils.weights import load_model_weights
@@ -443,7 +477,7 @@ def main(argv=None) -> int:
                 log.append(rec_)
                 print(json.dumps(rec_), flush=True)
             if it % args.eval_every == 0 or it == args.steps:
-                ev = evaluate(det, rec, device, seeds=[900_001, 900_002, 900_003, 900_004], verbose=True)
+                ev = evaluate(det, rec, device, seeds=[900_001, 900_002, 900_003, 900_004], verbose=True, formula_weights=fw)
                 print(json.dumps({"step": it, "eval": ev}), flush=True)
                 save_bf16(det, dp)
                 save_bf16(rec, rp)
@@ -451,7 +485,8 @@ def main(argv=None) -> int:
     finally:
         prod.stop()
         alive.set()
-    ev = evaluate(det, rec, device, seeds=[900_001, 900_002, 900_003, 900_004, 900_005, 900_006, 900_007, 900_008], verbose=True)
+    ev = evaluate(det, rec, device, seeds=[900_001, 900_002, 900_003, 900_004, 900_005, 900_006, 900_007, 900_008], verbose=True,
+                  formula_weights=fw)
     save_bf16(det, dp)
     save_bf16(rec, rp)
     write_meta(args.out, it, ev, log)

@@ -110,3 +110,36 @@ def test_figure_is_found_kept_out_of_the_text_and_written(pipe):
     # text: the figure contributes no lines, the caption and both neighbours are read
     got, want = "\n".join(l.text.strip() for l in page.lines), "\n".join(s.strip() for s in tr.texts)
     assert _cer(got, want) < 0.03, (_cer(got, want), got[:300], want[:300])
+
+
+def test_display_formulas_are_found_read_and_kept_in_order(pipe):
+    """Display formulas (synthetic grammar, mathtext rendering): the block head finds them, the formula recogniser
+    turns each crop into LaTeX, the content list carries them as equation items between the right paragraphs, and
+    the text around them is still read."""
+    if pipe.engine.formula_rec is None:
+        pytest.skip("no formula recogniser weights shipped")
+    pg, tr = synth.render_layout_page(424_245, layout="single", fonts=["DejaVuSerif.ttf"], formulas=0.9, noise=2.0)
+    assert tr.formulas.shape[0] >= 3
+    doc = pipe.process_pdf(synth.make_scanned_pdf([pg], codec="jpeg", restart_blocks=0), "formulas")
+    page = doc.pages[0]
+    eqs = [l for l in page.lines if l.kind == "equation"]
+    text = [l for l in page.lines if l.kind == "text"]
+    assert abs(len(eqs) - tr.formulas.shape[0]) <= 1, (len(eqs), tr.formulas.shape[0])
+    cers, matched = [], 0
+    for t, latex in zip(tr.formulas, tr.formula_texts):
+        best = max(eqs, key=lambda l: max(0.0, min(l.box[2], t[2]) - max(l.box[0], t[0])) * max(0.0, min(l.box[3], t[3]) - max(l.box[1], t[1])))
+        ix = max(0.0, min(best.box[2], t[2]) - max(best.box[0], t[0])) * max(0.0, min(best.box[3], t[3]) - max(best.box[1], t[1]))
+        iou = ix / ((best.box[2] - best.box[0]) * (best.box[3] - best.box[1]) + (t[2] - t[0]) * (t[3] - t[1]) - ix)
+        if iou > 0.5:
+            matched += 1
+            cers.append(min(1.0, _cer(best.text, latex)))
+        else:
+            cers.append(1.0)
+    print("formula CERs:", [round(c, 2) for c in cers], [l.text for l in eqs][:3], tr.formula_texts[:3])
+    assert matched >= tr.formulas.shape[0] - 1
+    assert float(np.mean(cers)) < 0.3, cers
+    got, want = "\n".join(l.text.strip() for l in text), "\n".join(s.strip() for s in tr.texts)
+    assert _cer(got, want) < 0.03, (_cer(got, want), got[:300], want[:300])
+    kinds = [it["type"] for it in doc.content_list]
+    assert kinds.count("equation") == len(eqs) and all(it["text"].startswith("$$ ") for it in doc.content_list if it["type"] == "equation")
+    assert "$$" in doc.text
