@@ -53,6 +53,16 @@ class TrOCRConfig:
     bos: int = 0
     pad: int = 1
     eos: int = 2
+    # decoder variant.  Defaults = this repository's own layout (pre-LN, final LN).  The published TrOCR decoder
+    # (transformers' TrOCRDecoder) is post-LN with a LayerNorm on the embeddings, learned positions shifted by two and
+    # no final LN: ``hf_trocr_config`` sets these, ``tools/download_models.convert_hf_trocr`` maps its tensors.
+    post_ln: bool = False
+    embed_ln: bool = False
+    pos_offset: int = 0
+    final_ln: bool = True
+    embed_scale: float = 1.0
+    act: str = "gelu"           # "gelu" | "relu" (decoder feed-forward)
+    enc_ln_eps: float = 1e-5    # LayerNorm epsilon of the encoder (transformers' ViT: 1e-12)
 
     @property
     def tokens(self) -> int:
@@ -69,15 +79,27 @@ class TrOCRConfig:
 FORMULA_HW = (96, 384)
 
 
+def hf_trocr_config(image_size: int = 384, patch: int = 16, enc_dim: int = 768, enc_layers: int = 12, enc_heads: int = 12,
+                    enc_mlp: int = 3072, dec_dim: int = 1024, dec_layers: int = 12, dec_heads: int = 16, dec_ffn: int = 4096,
+                    vocab: int = 50265, max_len: int = 512, act: str = "gelu", scale_embedding: bool = False,
+                    layernorm_embedding: bool = True) -> TrOCRConfig:
+    """The layout of the published TrOCR checkpoints (defaults: microsoft/trocr-base-*)."""
+    return TrOCRConfig(image_size=image_size, patch=patch, enc_dim=enc_dim, enc_layers=enc_layers, enc_heads=enc_heads,
+                       enc_mlp=enc_mlp, dec_dim=dec_dim, dec_layers=dec_layers, dec_heads=dec_heads, dec_ffn=dec_ffn,
+                       vocab=vocab, max_len=max_len, bos=0, pad=1, eos=2, post_ln=True, embed_ln=layernorm_embedding,
+                       pos_offset=2, final_ln=False, embed_scale=(dec_dim ** 0.5 if scale_embedding else 1.0), act=act,
+                       enc_ln_eps=1e-12)
+
+
 def formula_config() -> TrOCRConfig:
     return TrOCRConfig(image_size=192, enc_dim=256, enc_layers=4, enc_heads=4, enc_mlp=1024, dec_dim=256, dec_layers=4,
                        dec_heads=4, dec_ffn=1024, vocab=272, max_len=128)
 
 
 class _EncLayer(nn.Module):
-    def __init__(self, d: int, mlp: int):
+    def __init__(self, d: int, mlp: int, eps: float = 1e-5):
         super().__init__()
-        self.ln1, self.ln2 = nn.LayerNorm(d), nn.LayerNorm(d)
+        self.ln1, self.ln2 = nn.LayerNorm(d, eps=eps), nn.LayerNorm(d, eps=eps)
         self.qkv, self.proj = nn.Linear(d, 3 * d), nn.Linear(d, d)
         self.fc1, self.fc2 = nn.Linear(d, mlp), nn.Linear(mlp, d)
 
@@ -107,12 +129,13 @@ class TrOCR(nn.Module):
         self.patch_embed = nn.Conv2d(3, cfg.enc_dim, cfg.patch, cfg.patch)
         self.cls = nn.Parameter(torch.zeros(1, 1, cfg.enc_dim))
         self.enc_pos = nn.Parameter(torch.randn(1, cfg.tokens, cfg.enc_dim) * 0.02)
-        self.enc = nn.ModuleList([_EncLayer(cfg.enc_dim, cfg.enc_mlp) for _ in range(cfg.enc_layers)])
-        self.enc_ln = nn.LayerNorm(cfg.enc_dim)
+        self.enc = nn.ModuleList([_EncLayer(cfg.enc_dim, cfg.enc_mlp, cfg.enc_ln_eps) for _ in range(cfg.enc_layers)])
+        self.enc_ln = nn.LayerNorm(cfg.enc_dim, eps=cfg.enc_ln_eps)
         self.tok = nn.Embedding(cfg.vocab, cfg.dec_dim)
-        self.pos = nn.Embedding(cfg.max_len, cfg.dec_dim)
+        self.pos = nn.Embedding(cfg.max_len + cfg.pos_offset, cfg.dec_dim)
+        self.emb_ln = nn.LayerNorm(cfg.dec_dim) if cfg.embed_ln else None
         self.dec = nn.ModuleList([_DecLayer(cfg.dec_dim, cfg.enc_dim, cfg.dec_ffn) for _ in range(cfg.dec_layers)])
-        self.dec_ln = nn.LayerNorm(cfg.dec_dim)
+        self.dec_ln = nn.LayerNorm(cfg.dec_dim) if cfg.final_ln else None
         self.lm_head = nn.Linear(cfg.dec_dim, cfg.vocab, bias=False)
         for m in self.modules():
             if isinstance(m, nn.Linear):
@@ -149,14 +172,23 @@ class TrOCR(nn.Module):
         """Teacher-forced decoder: tokens [B, L] -> logits [B, L, vocab]."""
         cfg = self.cfg
         L = tokens.shape[1]
-        x = self.tok(tokens) + self.pos(torch.arange(L, device=tokens.device))[None]
+        act = F.gelu if cfg.act == "gelu" else F.relu
+        x = self.tok(tokens) * cfg.embed_scale + self.pos(torch.arange(L, device=tokens.device) + cfg.pos_offset)[None]
+        if self.emb_ln is not None:
+            x = self.emb_ln(x)
         for l in self.dec:
-            q, k, v = l.qkv(l.ln1(x)).chunk(3, -1)
-            x = x + l.proj(T.attention_reference(q, k, v, cfg.dec_heads, 0.125, causal=True))
             xk, xv = l.xkv(memory).chunk(2, -1)
-            x = x + l.xproj(T.attention_reference(l.xq(l.ln2(x)), xk, xv, cfg.dec_heads, 0.125))
-            x = x + l.fc2(F.gelu(l.fc1(l.ln3(x))))
-        return self.lm_head(self.dec_ln(x))
+            if cfg.post_ln:
+                q, k, v = l.qkv(x).chunk(3, -1)
+                x = l.ln1(x + l.proj(T.attention_reference(q, k, v, cfg.dec_heads, 0.125, causal=True)))
+                x = l.ln2(x + l.xproj(T.attention_reference(l.xq(x), xk, xv, cfg.dec_heads, 0.125)))
+                x = l.ln3(x + l.fc2(act(l.fc1(x))))
+            else:
+                q, k, v = l.qkv(l.ln1(x)).chunk(3, -1)
+                x = x + l.proj(T.attention_reference(q, k, v, cfg.dec_heads, 0.125, causal=True))
+                x = x + l.xproj(T.attention_reference(l.xq(l.ln2(x)), xk, xv, cfg.dec_heads, 0.125))
+                x = x + l.fc2(act(l.fc1(l.ln3(x))))
+        return self.lm_head(self.dec_ln(x) if self.dec_ln is not None else x)
 
     @torch.no_grad()
     def generate_reference(self, x: torch.Tensor, max_len: int) -> torch.Tensor:
@@ -185,9 +217,10 @@ class TrOCR(nn.Module):
         pk["dec"] = [dict(ln1=_ln(l.ln1), ln2=_ln(l.ln2), ln3=_ln(l.ln3), qkv=_pk(l.qkv), proj=_pk(l.proj),
                           xq=_pk(l.xq), xkv=_pk(l.xkv), xproj=_pk(l.xproj), fc1=_pk(l.fc1), fc2=_pk(l.fc2))
                      for l in self.dec]
-        pk["dec_ln"] = _ln(self.dec_ln)
-        pk["tok"] = self.tok.weight.detach().to(torch.bfloat16).contiguous()
-        pk["dpos"] = self.pos.weight.detach().to(torch.bfloat16).contiguous()
+        pk["dec_ln"] = _ln(self.dec_ln) if self.dec_ln is not None else None
+        pk["emb_ln"] = _ln(self.emb_ln) if self.emb_ln is not None else None
+        pk["tok"] = (self.tok.weight.detach() * cfg.embed_scale).to(torch.bfloat16).contiguous()
+        pk["dpos"] = self.pos.weight.detach()[cfg.pos_offset:].to(torch.bfloat16).contiguous()
         lw = torch.zeros(cfg.vocab_padded, cfg.dec_dim, device=dev)
         lw[: cfg.vocab] = self.lm_head.weight.detach().float()
         lb = torch.full((cfg.vocab_padded,), -1e4, device=dev)
@@ -209,36 +242,47 @@ class TrOCR(nn.Module):
         pe = conv2d_nhwc(x, pk["patch"][0], pk["patch"][1], stride=cfg.patch)      # [B, g, g, D]
         h[:, 1:] = pe.reshape(B, n - 1, cfg.enc_dim) + pk["pos"]
         h[:, :1] = pk["cls_pos"]
+        eps = cfg.enc_ln_eps
         for l in pk["enc"]:
-            y = T.layernorm(h, *l["ln1"])
+            y = T.layernorm(h, *l["ln1"], eps=eps)
             qkv = linear_bf16(y, *l["qkv"])
             d = cfg.enc_dim
             a = T.attention(qkv[..., :d], qkv[..., d : 2 * d], qkv[..., 2 * d :], cfg.enc_heads)
             h = linear_bf16(a, *l["proj"], res=h)
-            y = T.layernorm(h, *l["ln2"])
+            y = T.layernorm(h, *l["ln2"], eps=eps)
             y = linear_bf16(y, *l["fc1"], act="gelu")
             h = linear_bf16(y, *l["fc2"], res=h)
-        return T.layernorm(h, *pk["enc_ln"])
+        return T.layernorm(h, *pk["enc_ln"], eps=eps)
 
     def _decode_step(self, st: "_DecodeState") -> None:
         """One greedy step on the static state (tokens, t, caches) - the body that gets graph-captured."""
         cfg, pk = self.cfg, self._pk
         d = cfg.dec_dim
         x = T.embed_rows(st.tokens, pk["tok"], pk["dpos"], st.t)
+        if pk["emb_ln"] is not None:
+            x = T.layernorm(x, *pk["emb_ln"])
+        post = cfg.post_ln
         for li, l in enumerate(pk["dec"]):
-            y = T.layernorm(x, *l["ln1"])
+            y = x if post else T.layernorm(x, *l["ln1"])
             qkv = linear_bf16(y, *l["qkv"])
             a = T.attention_decode(qkv[:, :d], st.k_self[li], st.v_self[li], cfg.dec_heads,
                                    k_new=qkv[:, d : 2 * d], v_new=qkv[:, 2 * d :], t=st.t)
             x = linear_bf16(a, *l["proj"], res=x)
-            y = T.layernorm(x, *l["ln2"])
+            if post:
+                x = T.layernorm(x, *l["ln1"])
+            y = x if post else T.layernorm(x, *l["ln2"])
             q = linear_bf16(y, *l["xq"])
             a = T.attention_decode(q, st.k_cross[li], st.v_cross[li], cfg.dec_heads, klen=cfg.tokens)
             x = linear_bf16(a, *l["xproj"], res=x)
-            y = T.layernorm(x, *l["ln3"])
-            y = linear_bf16(y, *l["fc1"], act="gelu")
+            if post:
+                x = T.layernorm(x, *l["ln2"])
+            y = x if post else T.layernorm(x, *l["ln3"])
+            y = linear_bf16(y, *l["fc1"], act=cfg.act)
             x = linear_bf16(y, *l["fc2"], res=x)
-        x = T.layernorm(x, *pk["dec_ln"])
+            if post:
+                x = T.layernorm(x, *l["ln3"])
+        if pk["dec_ln"] is not None:
+            x = T.layernorm(x, *pk["dec_ln"])
         logits = linear_bf16(x, *pk["lm"])
         idx, prob = ctc_ops.row_argmax(logits)
         st.tokens.copy_(idx)

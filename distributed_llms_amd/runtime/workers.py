@@ -70,6 +70,13 @@ def build_engine(device: str, engine_spec: Dict) -> "object":
         rec = TrOCR(TrOCRConfig(image_size=64, enc_dim=128, enc_layers=1, enc_heads=2, enc_mlp=256, dec_dim=128, dec_layers=1,
                                 dec_heads=2, dec_ffn=256, vocab=272, max_len=16) if tiny else None)
     wd = engine_spec.get("weights_dir")
+    if kind == "trocr" and wd and os.path.exists(os.path.join(str(wd), "trocr_config.json")) and engine_spec.get("model", "full") == "full":
+        # a converted public checkpoint (tools/download_models.py) brings its own geometry and decoder variant
+        import json
+
+        from ..models.trocr import TrOCR, TrOCRConfig
+
+        rec = TrOCR(TrOCRConfig(**json.load(open(os.path.join(str(wd), "trocr_config.json")))))
     if wd and str(wd).lower() != "none" and engine_spec.get("model", "full") == "full":
         from ..utils.weights import load_model_weights
 

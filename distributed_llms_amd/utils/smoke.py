@@ -16,13 +16,14 @@ def run_smoke() -> None:
         from ..ops import _loader
 
         _loader.lib()  # fail loudly if the HIP kernel library is missing on a GPU box
-    # ---- inference: 2-page scanned PDF (JPEG, restart markers) -> text through the full pipeline
+    # ---- inference: 2-page scanned PDF (JPEG without restart markers: the self-synchronising GPU decoder) -> text
+    #      through the full pipeline
     pages, priors = [], []
     for i in range(2):
         pg, truth = synth.render_page(i, size=(1240, 1754), font_px=28, margin=110)
         pages.append(pg)
         priors.append(truth.boxes)
-    pdf = synth.make_scanned_pdf(pages, codec="jpeg", dpi=150)
+    pdf = synth.make_scanned_pdf(pages, codec="jpeg", dpi=150, restart_blocks=0)
     eng = OcrEngine(dev, cfg=EngineConfig(max_batch_pages=2, det_limit_side=960))
     pipe = DocumentPipeline(eng, decode_threads=2)
     doc = pipe.process_pdf(pdf, "smoke", layout_priors=priors)
