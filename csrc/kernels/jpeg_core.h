@@ -172,50 +172,39 @@ JPEG_HD int sub_decode(const JpegImageDesc& d, const int j, SubState& st, const 
   }
   while (consumed < nbits_sub) {
     const bool luma = b < yblocks;
+    const bool dc = k == 0;
     br.refill();
-    if (k == 0) {
-      const int t = luma ? 0 : 2;
-      const uint32_t e0 = s_lut[t][br.peek(JPEG_LUT_BITS)];
-      int sz;
-      if (e0) { br.skip(e0 >> 8); consumed += e0 >> 8; sz = e0 & 15; }
-      else {
-        int len = JPEG_LUT_BITS + 1, code = (int)br.peek(len);
-        while (len <= 16 && code > tb->maxcode[t][len]) { ++len; code = (int)br.peek(len); }
-        if (len > 16) { br.skip(16); consumed += 16; sz = 0; }
-        else { br.skip(len); consumed += len; sz = tb->vals[t][(code + tb->valoff[t][len]) & 0xff] & 15; }
-      }
-      br.refill();
-      const int diff = receive_extend(br, sz);
-      consumed += sz;
-      if (WRITE && luma && blk0 + done < d.total_blocks) d.dcdiff[(long long)mcu * yblocks + b] = diff;
+    // One code path for DC and AC symbols: lanes of a wave sit at different coefficient indices, and a branch per
+    // symbol kind would run both kinds for every lane.  A DC symbol is (run 0, size), so the AC arithmetic covers it.
+    const int t = (luma ? 0 : 2) + (dc ? 0 : 1);
+    const uint32_t e0 = s_lut[t][br.peek(JPEG_LUT_BITS)];
+    int rs, len;
+    if (e0) { len = (int)(e0 >> 8); rs = (int)(e0 & 0xff); }
+    else {
+      len = JPEG_LUT_BITS + 1;
+      int code = (int)br.peek(len);
+      while (len <= 16 && code > tb->maxcode[t][len]) { ++len; code = (int)br.peek(len); }
+      if (len > 16) { len = 16; rs = 0; }
+      else rs = tb->vals[t][(code + tb->valoff[t][len]) & 0xff];
+    }
+    br.skip(len);
+    const int r = rs >> 4, sz = rs & 15;
+    const int v = receive_extend(br, sz);              // >= 16 bits are left after the code word: no refill needed
+    consumed += len + sz;
+    if (dc) {
+      if (WRITE && luma && blk0 + done < d.total_blocks) d.dcdiff[(long long)mcu * yblocks + b] = v;
       k = 1;
+    } else if (sz == 0) {
+      k = (r == 15) ? k + 16 : 64;                      // ZRL or end of block
     } else {
-      const int t = luma ? 1 : 3;
-      const uint32_t e0 = s_lut[t][br.peek(JPEG_LUT_BITS)];
-      int rs;
-      if (e0) { br.skip(e0 >> 8); consumed += e0 >> 8; rs = e0 & 0xff; }
-      else {
-        int len = JPEG_LUT_BITS + 1, code = (int)br.peek(len);
-        while (len <= 16 && code > tb->maxcode[t][len]) { ++len; code = (int)br.peek(len); }
-        if (len > 16) { br.skip(16); consumed += 16; rs = 0; }
-        else { br.skip(len); consumed += len; rs = tb->vals[t][(code + tb->valoff[t][len]) & 0xff]; }
+      k += r;
+      if (WRITE && luma && k < 64 && blk0 + done < d.total_blocks) {
+        const int bx = mx * d.hs0 + (b % d.hs0), by = my * d.vs0 + (b / d.hs0);
+        const int z = s_zz[k];
+        const int q = v * (int)s_qt[z];
+        d.coef[((long long)by * d.Wb + bx) * 64 + z] = (int16_t)jpeg_imax(-32768, jpeg_imin(32767, q));
       }
-      const int r = rs >> 4, sz = rs & 15;
-      if (sz == 0) {
-        k = (r == 15) ? k + 16 : 64;                    // ZRL or end of block
-      } else {
-        k += r;
-        br.refill();
-        const int v = receive_extend(br, sz);
-        consumed += sz;
-        if (WRITE && luma && k < 64 && blk0 + done < d.total_blocks) {
-          const int bx = mx * d.hs0 + (b % d.hs0), by = my * d.vs0 + (b / d.hs0);
-          const int z = s_zz[k];
-          const int q = v * (int)s_qt[z];
-          d.coef[((long long)by * d.Wb + bx) * 64 + z] = (int16_t)jpeg_imax(-32768, jpeg_imin(32767, q));
-        }
-        ++k;
-      }
+      ++k;
     }
     if (k >= 64) {                                       // block complete
       k = 0;

@@ -123,7 +123,8 @@ def build_kernels(force: bool = False, jobs: int = 8, verbose: bool = False) -> 
 
 def _build_cpp(name: str, subdir: str, libs: List[str], force: bool, jobs: int, verbose: bool) -> Path:
     srcs = sorted((CSRC / subdir).glob("*.cpp"))
-    hdrs = sorted((CSRC / subdir).glob("*.h"))
+    # the PDF library includes the JPEG decode core it shares with the kernels (csrc/kernels/jpeg_core.h)
+    hdrs = sorted((CSRC / subdir).glob("*.h")) + sorted((CSRC / "kernels").glob("*core.h"))
     out = LIB_DIR / f"libdlamd_{name}.so"
     digest = _sha(list(srcs) + list(hdrs), " ".join(CXX_FLAGS + libs))
     if not force and _up_to_date(name, digest, out):
