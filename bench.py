@@ -74,6 +74,7 @@ def parse_args():
     ap.add_argument("--cpu", action="store_true", help="debug: tiny model on CPU")
     ap.add_argument("--stage-times", action="store_true")
     ap.add_argument("--slots", type=int, default=0, help="pipeline streams (0: engine default)")
+    ap.add_argument("--rec-quantum", type=int, default=0, help="width-bucket quantum of the recognizer crops (0: engine default)")
     ap.add_argument("--sequential", action="store_true",
                     help="finish each document before the next one starts (default: the K documents are queued back to back "
                          "through one engine pipeline, as a worker with a queue of uploads runs them)")
@@ -192,6 +193,8 @@ def main():
     cfg = EngineConfig(max_batch_pages=args.batch_pages, use_hip_graphs=not args.no_graphs)
     if args.slots > 0:
         cfg.pipeline_slots = args.slots
+    if args.rec_quantum > 0:
+        cfg.rec_width_quantum = args.rec_quantum
     det = rec = None
     size = synth.A4_300DPI
     if not use_gpu:

@@ -48,6 +48,28 @@ def main():
             except Exception as e:  # noqa: BLE001
                 row[str(cfg)] = str(e)[:60]
         print(json.dumps(row), flush=True)
+    # FPN laterals (1x1 into 256 channels, + nearest-2x residual): streaming kernel (9100) against the generic tiles
+    for name, H, W, Cin in (("in2 64->256 @1/4 +up2", 336, 240, 64), ("in3 128->256 @1/8 +up2", 168, 120, 128)):
+        x = torch.randn(B, H, W, Cin, device=dev).to(torch.bfloat16)
+        w = (torch.randn(256, 1, 1, Cin, device=dev) * 0.05).to(torch.bfloat16)
+        b = torch.zeros(256, device=dev)
+        r = torch.randn(B, H // 2, W // 2, 256, device=dev).to(torch.bfloat16)
+        out = torch.empty(B, H, W, 256, device=dev, dtype=torch.bfloat16)
+        gb = (x.numel() + out.numel() + r.numel()) * 2 / 1e9
+        row = {"layer": name, "gbytes": round(gb, 3)}
+        ref = None
+        for cfg in (9100, 3900, 1128):
+            try:
+                y = C.conv2d_nhwc(x, w, b, res=r, res_mode=C.RES_UP2, out=out, cfg=cfg)
+                if ref is None:
+                    ref = y.float().clone()
+                else:
+                    assert (y.float() - ref).abs().max().item() < 0.1, cfg
+                ms = timed(lambda: C.conv2d_nhwc(x, w, b, res=r, res_mode=C.RES_UP2, out=out, cfg=cfg))
+                row[str(cfg)] = {"ms": round(ms, 4), "gbps": round(gb / ms * 1e3, 1)}
+            except Exception as e:  # noqa: BLE001
+                row[str(cfg)] = str(e)[:60]
+        print(json.dumps(row), flush=True)
 
 
 if __name__ == "__main__":

@@ -41,5 +41,6 @@ print(f"total conv/linear launch time for 100 pages: {tot:.1f} ms in {sum(v[0] f
 print(f"{'M':>9s} {'N':>5s} {'K':>5s} {'kind':28s} {'calls':>5s} {'ms':>8s} {'TF':>7s} {'GB/s(in+out)':>12s}")
 for (M, N, K, kind), (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     tf = 2.0 * M * N * K * n / (ms * 1e-3) / 1e12
-    gbs = (M * N * 2 + M * K * 2 / max(1, int(kind[0]) * int(kind[2]))) * n / (ms * 1e-3) / 1e9
+    taps = int(kind[0]) * int(kind[2]) if kind[0].isdigit() and kind[2].isdigit() else 1
+    gbs = (M * N * 2 + M * K * 2 / max(1, taps)) * n / (ms * 1e-3) / 1e9
     print(f"{M:9d} {N:5d} {K:5d} {kind:28s} {n:5d} {ms:8.2f} {tf:7.1f} {gbs:12.0f}")

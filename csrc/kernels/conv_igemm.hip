@@ -935,6 +935,13 @@ bool dlamd_conv_stem_serves(int Cin, int stride, int Cout);
 int dlamd_conv_stem(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int stride, int Ho,
                     int Wo, int Cout, int act, int y_cstride, int y_coff, hipStream_t stream);
 
+// conv_lateral.hip: streaming 1x1 kernel for Cin 64 / 128 -> 256 channels (FPN laterals)
+bool dlamd_conv_lateral_serves(int Cin, int x_cstride, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                               int res_cstride, int res_mode, int out_mode, int y_cstride, int y_coff, int y_f32);
+int dlamd_conv_lateral(const void* x, const void* w, const float* bias, const void* res, void* y, int M, int H, int W,
+                       int Cin, int x_cstride, int act, int res_mode, int res_cstride, int y_cstride, int y_coff,
+                       hipStream_t stream);
+
 extern "C" int dlamd_conv2d(const void* x, const void* w, const float* bias, const void* res, void* y, void* mask,
                             int B, int H, int W, int Cin, int x_cstride, int Cout, int kh, int kw, int sh, int sw,
                             int ph, int pw, int act, int res_mode, int res_cstride, int out_mode, int out_f,
@@ -988,6 +995,14 @@ extern "C" int dlamd_conv2d(const void* x, const void* w, const float* bias, con
   if (stem_ok && (cfg == 0 || cfg == 9008))
     return dlamd_conv_stem(x, w, bias, y, B, H, W, Cin, sh, a.Ho, a.Wo, Cout, act, y_cstride, y_coff, stream);
   if (cfg == 9008) return -13;
+  // Shallow-K 1x1 into 256 channels over a large map (FPN lateral of the quarter-scale level): weights resident in
+  // LDS, pixels streamed (cfg 9100 forces it; auto mode from 32 k pixels up, below that the prologue shows)
+  const bool lat_ok = dlamd_conv_lateral_serves(Cin, x_cstride, Cout, kh, kw, sh, sw, ph, pw, res_cstride, a.res_mode,
+                                                out_mode, y_cstride, y_coff, y_f32);
+  if (lat_ok && ((cfg == 0 && a.M >= 32768) || cfg == 9100))
+    return dlamd_conv_lateral(x, w, bias, a.res_mode ? res : nullptr, y, a.M, a.Ho, a.Wo, Cin, x_cstride, act,
+                              a.res_mode, res_cstride, y_cstride, y_coff, stream);
+  if (cfg == 9100) return -13;
   // cfg 3xxx forces / 39xx forbids the LDS-patch 3x3 kernel (benchmarks and tests); default: use it when it applies
   const bool patch_ok = a.wfrag && kh == 3 && kw == 3 && ph == 1 && pw == 1 && sw == 1 && (sh == 1 || sh == 2) &&
                         Cin % 64 == 0 && x_cstride == Cin && (long long)B * a.Ho * a.Wo < 0x7fffffffLL;

@@ -241,15 +241,82 @@ __global__ __launch_bounds__(256) void ccl_stats_kernel(const bf16_t* __restrict
   }
 }
 
+// Page skew: every wide component votes for the angle of its principal axis with its width; the page's angle is the
+// mode of that histogram.  One angle per page is far more precise than any single blob's second moments (a text blob
+// is not a clean rectangle: ascenders, descenders and ragged ends pull its axis by tenths of a degree, which over a
+// 2000-pixel line is a dozen pixels of drift in the crop).
+#define ANG_BINS 401            // 0.1 degree bins over +-20 degrees
+#define ANG_BIN_RAD 0.0017453292f
+
 __global__ void stats_init_kernel(int* __restrict__ stats, int* __restrict__ ncomp, int* __restrict__ nbox, int n,
-                                  int B) {
+                                  int B, int* __restrict__ hist) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B) { ncomp[i] = 0; nbox[i] = 0; }
+  if (hist && i < B * ANG_BINS) hist[i] = 0;
   if (i >= n) return;
   int* s = stats + (long long)i * STAT_STRIDE;
   s[0] = 0x7fffffff; s[1] = 0x7fffffff; s[2] = -1; s[3] = -1; s[4] = 0; s[5] = 0;
 #pragma unroll
   for (int k = 6; k < STAT_STRIDE; ++k) s[k] = 0;
+}
+
+// principal-axis angle of component `s` (radians, det-map frame) and the eigenvalues of its covariance
+__device__ __forceinline__ double component_axis(const int* __restrict__ s, int cnt, double& l_major, double& l_minor,
+                                                 double& mx, double& my) {
+  const long long* m = reinterpret_cast<const long long*>(s + 6);
+  const double n = (double)cnt;
+  mx = (double)m[0] / n;
+  my = (double)m[1] / n;
+  const double u20 = (double)m[2] / n - mx * mx, u02 = (double)m[3] / n - my * my, u11 = (double)m[4] / n - mx * my;
+  const double r = sqrt(0.25 * (u20 - u02) * (u20 - u02) + u11 * u11);
+  l_major = 0.5 * (u20 + u02) + r;
+  l_minor = fmax(0.5 * (u20 + u02) - r, 0.0);
+  return 0.5 * atan2(2.0 * u11, u20 - u02);
+}
+
+__global__ void angle_vote_kernel(const int* __restrict__ stats, const int* __restrict__ ncomp, int* __restrict__ hist,
+                                  int maxc, float box_thresh, int min_size, float max_angle) {
+  int cidx = blockIdx.x * blockDim.x + threadIdx.x;
+  int b = blockIdx.y;
+  if (cidx >= min(ncomp[b], maxc)) return;
+  const int* s = stats + ((long long)b * maxc + cidx) * STAT_STRIDE;
+  const int cnt = s[4];
+  if (cnt <= 0) return;
+  const float w = (float)(s[2] + 1 - s[0]), h = (float)(s[3] + 1 - s[1]);
+  if (fminf(w, h) < (float)min_size || w < 3.f * h) return;
+  if (__builtin_bit_cast(float, s[5]) / (float)cnt < box_thresh) return;
+  double l1, l2, mx, my;
+  const double th = component_axis(s, cnt, l1, l2, mx, my);
+  if (fabs(th) > (double)max_angle || l1 < 64.0 * (l2 + 1.0 / 12.0)) return;   // length >= 8 x thickness
+  const int bin = (int)lrint(th / (double)ANG_BIN_RAD) + ANG_BINS / 2;
+  if (bin >= 0 && bin < ANG_BINS) atomicAdd(&hist[b * ANG_BINS + bin], (int)w);
+}
+
+// one wave per page: mode of the 3-bin-smoothed histogram, refined by the centroid of those three bins
+__global__ __launch_bounds__(64) void angle_mode_kernel(const int* __restrict__ hist, float* __restrict__ page_angle) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int* h = hist + b * ANG_BINS;
+  long long best = -1;
+  int best_bin = ANG_BINS / 2;
+  for (int i = lane; i < ANG_BINS; i += 64) {
+    const long long v = (long long)h[i] + (i > 0 ? h[i - 1] : 0) + (i + 1 < ANG_BINS ? h[i + 1] : 0);
+    if (v > best) { best = v; best_bin = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const long long ov = __shfl_xor(best, o, 64);
+    const int ob = __shfl_xor(best_bin, o, 64);
+    if (ov > best || (ov == best && ob < best_bin)) { best = ov; best_bin = ob; }
+  }
+  if (lane == 0) {
+    float a = 0.f;
+    if (best > 0) {
+      const float c0 = best_bin > 0 ? (float)h[best_bin - 1] : 0.f, c1 = (float)h[best_bin],
+                  c2 = best_bin + 1 < ANG_BINS ? (float)h[best_bin + 1] : 0.f;
+      a = ((float)(best_bin - ANG_BINS / 2) + (c2 - c0) / (c0 + c1 + c2)) * ANG_BIN_RAD;
+    }
+    page_angle[b] = a;
+  }
 }
 
 // page_scale: [B, 2] float (sx, sy): multiply det-map coords to get page pixel coords.
@@ -262,7 +329,8 @@ __global__ void stats_init_kernel(int* __restrict__ stats, int* __restrict__ nco
 __global__ void box_finalize_kernel(const int* __restrict__ stats, const int* __restrict__ ncomp,
                                     const float* __restrict__ page_scale, const int* __restrict__ valid,
                                     float* __restrict__ boxes, int* __restrict__ nbox, int maxc, int max_boxes,
-                                    float box_thresh, float unclip_ratio, int min_size, float max_angle, int H, int W) {
+                                    float box_thresh, float unclip_ratio, int min_size, float max_angle,
+                                    const float* __restrict__ page_angle, int H, int W) {
   int cidx = blockIdx.x * blockDim.x + threadIdx.x;
   int b = blockIdx.y;
   int nc = min(ncomp[b], maxc);
@@ -276,20 +344,17 @@ __global__ void box_finalize_kernel(const int* __restrict__ stats, const int* __
   if (fminf(w, h) < (float)min_size) return;
   if (score < box_thresh) return;
   const float sx = page_scale ? page_scale[b * 2] : 1.f, sy = page_scale ? page_scale[b * 2 + 1] : 1.f;
-  // orientation: principal axis of the pixel distribution
+  // orientation: the page's skew (angle_mode_kernel) for every wide component; a wide component whose own principal
+  // axis disagrees with it by more than 3 degrees (a rotated inset) keeps its own
   float angle = 0.f;
   double l_major = 0.0, l_minor = 0.0, mx = 0.0, my = 0.0;
   if (max_angle > 0.f && w >= 3.f * h) {
-    const long long* m = reinterpret_cast<const long long*>(s + 6);
-    const double n = (double)cnt;
-    mx = (double)m[0] / n;
-    my = (double)m[1] / n;
-    const double u20 = (double)m[2] / n - mx * mx, u02 = (double)m[3] / n - my * my, u11 = (double)m[4] / n - mx * my;
-    const double th = 0.5 * atan2(2.0 * u11, u20 - u02);
-    const double r = sqrt(0.25 * (u20 - u02) * (u20 - u02) + u11 * u11);
-    l_major = 0.5 * (u20 + u02) + r;
-    l_minor = fmax(0.5 * (u20 + u02) - r, 0.0);
-    if (fabs(th) <= (double)max_angle && fabs(th) >= 0.004 && l_major >= 16.0 * (l_minor + 1.0 / 12.0)) angle = (float)th;
+    const double th = component_axis(s, cnt, l_major, l_minor, mx, my);
+    const float pa = page_angle ? page_angle[b] : (float)th;
+    const bool own_ok = fabs(th) <= (double)max_angle && l_major >= 16.0 * (l_minor + 1.0 / 12.0);
+    float a = pa;
+    if (own_ok && l_major >= 64.0 * (l_minor + 1.0 / 12.0) && fabs(th - (double)pa) > 0.0524) a = (float)th;
+    if (fabsf(a) >= 0.004f && fabsf(a) <= max_angle) angle = a;
   }
   if (angle == 0.f) {
     float d = (w * h) * unclip_ratio / (2.f * (w + h));
@@ -330,17 +395,21 @@ __global__ void box_finalize_kernel(const int* __restrict__ stats, const int* __
 
 // mask: [B,H,W] u8, prob: [B,H,W] bf16.  Workspaces: parent, comp_id: [B,H,W] int32;
 // stats: [B,maxc,16] int32 (8-byte aligned); ncomp, nbox: [B] int32.  boxes: [B,max_boxes,8] float.
+// hist: [B, 401] int32 and page_angle: [B] float workspaces (needed when max_angle > 0).
 extern "C" int dlamd_db_postprocess(const void* mask, const void* prob, void* parent, void* comp_id, void* stats,
                                     void* ncomp, void* nbox, const float* page_scale, const int* valid, float* boxes,
                                     int B, int H, int W, int maxc, int max_boxes, float box_thresh,
-                                    float unclip_ratio, int min_size, float max_angle, hipStream_t stream) {
+                                    float unclip_ratio, int min_size, float max_angle, void* hist, float* page_angle,
+                                    hipStream_t stream) {
   if (B <= 0) return 0;
   if ((long long)H * W > 0x7fffffffLL || B > 65535) return -1;
   const int hw = H * W;
   {
+    if (max_angle > 0.f && (hist == nullptr || page_angle == nullptr)) return -2;
     int n = B * maxc;
-    int nb = (max(n, B) + 255) / 256;
-    hipLaunchKernelGGL(stats_init_kernel, dim3(nb), dim3(256), 0, stream, (int*)stats, (int*)ncomp, (int*)nbox, n, B);
+    int nb = (max(max(n, B), B * ANG_BINS) + 255) / 256;
+    hipLaunchKernelGGL(stats_init_kernel, dim3(nb), dim3(256), 0, stream, (int*)stats, (int*)ncomp, (int*)nbox, n, B,
+                       max_angle > 0.f ? (int*)hist : nullptr);
   }
   hipLaunchKernelGGL(ccl_init_local_kernel, dim3((hw + 255) / 256, B), dim3(256), 0, stream, (const uint8_t*)mask,
                      (int*)parent, hw, B, W);
@@ -351,8 +420,13 @@ extern "C" int dlamd_db_postprocess(const void* mask, const void* prob, void* pa
   dim3 grid_s((W + 63) / 64, (H + STAT_ROWS - 1) / STAT_ROWS, B);
   hipLaunchKernelGGL(ccl_stats_kernel, grid_s, dim3(256), 0, stream, (const bf16_t*)prob, (const int*)parent,
                      (const int*)comp_id, (int*)stats, H, W, maxc);
+  if (max_angle > 0.f) {
+    hipLaunchKernelGGL(angle_vote_kernel, dim3((maxc + 255) / 256, B), dim3(256), 0, stream, (const int*)stats,
+                       (const int*)ncomp, (int*)hist, maxc, box_thresh, min_size, max_angle);
+    hipLaunchKernelGGL(angle_mode_kernel, dim3(B), dim3(64), 0, stream, (const int*)hist, page_angle);
+  }
   hipLaunchKernelGGL(box_finalize_kernel, dim3((maxc + 255) / 256, B), dim3(256), 0, stream, (const int*)stats,
                      (const int*)ncomp, page_scale, valid, boxes, (int*)nbox, maxc, max_boxes, box_thresh,
-                     unclip_ratio, min_size, max_angle, H, W);
+                     unclip_ratio, min_size, max_angle, max_angle > 0.f ? (const float*)page_angle : nullptr, H, W);
   return DLAMD_CHECK_LAUNCH();
 }

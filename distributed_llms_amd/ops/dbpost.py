@@ -35,6 +35,47 @@ class DBPostConfig:
     max_angle_deg: float = 20.0     # wide components tilted less than this get an oriented box (0: upright boxes only)
 
 
+ANG_BINS = 401                       # 0.1 degree bins over +-20 degrees (db_postprocess.hip)
+ANG_BIN_RAD = float(np.float32(0.0017453292))
+
+
+def _axis(cnt, SX, SY, SXX, SYY, SXY):
+    n = float(cnt)
+    mx, my = SX / n, SY / n
+    u20, u02, u11 = SXX / n - mx * mx, SYY / n - my * my, SXY / n - mx * my
+    r = math.sqrt(0.25 * (u20 - u02) ** 2 + u11 * u11)
+    return 0.5 * math.atan2(2.0 * u11, u20 - u02), 0.5 * (u20 + u02) + r, max(0.5 * (u20 + u02) - r, 0.0), mx, my
+
+
+def _page_angle(stats, cfg: "DBPostConfig") -> float:
+    """Mode of the width-weighted histogram of principal-axis angles of the wide components (angle_vote_kernel +
+    angle_mode_kernel)."""
+    max_angle = math.radians(cfg.max_angle_deg)
+    hist = np.zeros(ANG_BINS, dtype=np.int64)
+    for (xmin, ymin, xmax, ymax, cnt, psum, *mom) in stats:
+        if cnt <= 0:
+            continue
+        w, h = float(xmax + 1 - xmin), float(ymax + 1 - ymin)
+        if min(w, h) < cfg.min_size or w < 3 * h or np.float32(psum) / np.float32(cnt) < np.float32(cfg.box_thresh):
+            continue
+        th, l1, l2, _, _ = _axis(cnt, *mom)
+        if abs(th) > max_angle or l1 < 64.0 * (l2 + 1.0 / 12.0):
+            continue
+        bn = int(np.rint(th / ANG_BIN_RAD)) + ANG_BINS // 2
+        if 0 <= bn < ANG_BINS:
+            hist[bn] += int(w)
+    sm = hist.copy()
+    sm[1:] += hist[:-1]
+    sm[:-1] += hist[1:]
+    if sm.max() <= 0:
+        return 0.0
+    k = int(np.argmax(sm))                      # first maximum = lowest bin on ties
+    c0 = float(hist[k - 1]) if k > 0 else 0.0
+    c1 = float(hist[k])
+    c2 = float(hist[k + 1]) if k + 1 < ANG_BINS else 0.0
+    return float((np.float32(k - ANG_BINS // 2) + np.float32(c2 - c0) / np.float32(c0 + c1 + c2)) * np.float32(ANG_BIN_RAD))
+
+
 def _finalize(stats, scale, valid, cfg: DBPostConfig, H: int, W: int) -> np.ndarray:
     """Shared arithmetic of box_finalize_kernel for one page (numpy).  ``stats`` rows: xmin, ymin, xmax, ymax, count,
     sum(prob), sum x, sum y, sum x^2, sum y^2, sum xy."""
@@ -43,6 +84,7 @@ def _finalize(stats, scale, valid, cfg: DBPostConfig, H: int, W: int) -> np.ndar
     vw, vh = (int(valid[0]), int(valid[1])) if valid is not None else (W, H)
     f32 = np.float32
     max_angle = math.radians(cfg.max_angle_deg)
+    pa = _page_angle(stats, cfg) if max_angle > 0 else 0.0
     for (xmin, ymin, xmax, ymax, cnt, psum, SX, SY, SXX, SYY, SXY) in stats:
         if cnt <= 0:
             continue
@@ -53,14 +95,13 @@ def _finalize(stats, scale, valid, cfg: DBPostConfig, H: int, W: int) -> np.ndar
             continue
         angle = 0.0
         if max_angle > 0 and w >= 3 * h:
-            n = float(cnt)
-            mx, my = SX / n, SY / n
-            u20, u02, u11 = SXX / n - mx * mx, SYY / n - my * my, SXY / n - mx * my
-            th = 0.5 * math.atan2(2.0 * u11, u20 - u02)
-            r = math.sqrt(0.25 * (u20 - u02) ** 2 + u11 * u11)
-            l_major, l_minor = 0.5 * (u20 + u02) + r, max(0.5 * (u20 + u02) - r, 0.0)
-            if 0.004 <= abs(th) <= max_angle and l_major >= 16.0 * (l_minor + 1.0 / 12.0):
-                angle = float(f32(th))
+            th, l_major, l_minor, mx, my = _axis(cnt, SX, SY, SXX, SYY, SXY)
+            own_ok = abs(th) <= max_angle and l_major >= 16.0 * (l_minor + 1.0 / 12.0)
+            a = pa
+            if own_ok and l_major >= 64.0 * (l_minor + 1.0 / 12.0) and abs(th - pa) > 0.0524:
+                a = float(f32(th))
+            if 0.004 <= abs(a) <= max_angle:
+                angle = float(f32(a))
         if angle == 0.0:
             d = (w * h) * f32(cfg.unclip_ratio) / (f32(2.0) * (w + h))
             x0, y0 = max(x0 - d, f32(0)), max(y0 - d, f32(0))
@@ -133,6 +174,8 @@ class DBPostWorkspace:
         self.ncomp = torch.empty((B,), dtype=torch.int32, device=device)
         self.nbox = torch.empty((B,), dtype=torch.int32, device=device)
         self.boxes = torch.empty((B, cfg.max_boxes, 8), dtype=torch.float32, device=device)
+        self.hist = torch.empty((B, ANG_BINS), dtype=torch.int32, device=device)        # page-skew votes
+        self.page_angle = torch.zeros((B,), dtype=torch.float32, device=device)
 
 
 def db_postprocess_gpu(
@@ -154,7 +197,7 @@ def db_postprocess_gpu(
         _loader.ptr(ws.stats), _loader.ptr(ws.ncomp), _loader.ptr(ws.nbox),
         _loader.ptr(page_scale), _loader.ptr(valid), _loader.ptr(ws.boxes),
         B, H, W, cfg.max_components, cfg.max_boxes, cfg.box_thresh, cfg.unclip_ratio, cfg.min_size,
-        math.radians(cfg.max_angle_deg), _loader.stream_ptr(),
+        math.radians(cfg.max_angle_deg), _loader.ptr(ws.hist), _loader.ptr(ws.page_angle), _loader.stream_ptr(),
     )
     _loader.check(rc, "dlamd_db_postprocess")
     return ws.boxes, ws.nbox

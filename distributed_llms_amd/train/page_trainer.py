@@ -235,6 +235,13 @@ def rec_batch(pages, model: CRNN, device, max_lines=64, jitter=0.12, angle_jitte
             j = np.random.uniform(-jitter, jitter, size=4) * r[3]
             cx, cy = r[0] + 0.5 * (j[0] + j[2]), r[1] + 0.5 * (j[1] + j[3])
             w, h = r[2] + (j[2] - j[0]), r[3] + (j[3] - j[1])
+            if np.random.rand() < 0.6:
+                # The detector's boxes are taller than the ink: the binarised kernel is ~2 detector pixels thicker
+                # than its target and the unclip multiplies that by 2.5, i.e. +10..16 page pixels whatever the font
+                # size - half the line height again for a 30-pixel font.  Train on that, not only on tight boxes.
+                grow = np.random.uniform(6.0, 22.0)
+                h += grow
+                w += np.random.uniform(0.3, 1.0) * grow
             if w < 8 or h < 8:
                 continue
             ang = float(r[4] + np.random.uniform(-angle_jitter, angle_jitter)) if r[4] != 0.0 else 0.0

@@ -166,6 +166,39 @@ def test_conv_residual_same_and_upsampled():
     _close(out, ref)
 
 
+def test_conv_lateral_streaming_kernel_residuals_slices_and_tails():
+    """Shallow-K 1x1 into 256 channels (cfg 9100): weights resident in LDS, pixels streamed through the waves."""
+    # 64 -> 256 with the nearest-2x residual, odd map sizes (partial last tile, coarse map rounded up), bias
+    x = _rand_bf16(2, 37, 45, 64, seed=40)
+    w = _rand_bf16(256, 1, 1, 64, scale=0.12, seed=41)
+    b = torch.randn(256) * 0.1
+    r2 = _rand_bf16(2, 19, 23, 256, seed=42)
+    ref = C.conv2d_nhwc_reference(x, w, b, res=r2, res_mode=C.RES_UP2, out_dtype=torch.float32)
+    out = C.conv2d_nhwc(x.to(DEV), w.to(DEV), b.to(DEV), res=r2.to(DEV), res_mode=C.RES_UP2, cfg=9100)
+    _close(out, ref)
+    # 128 -> 256, same-resolution residual, activation, input a channel slice of a wider tensor, output into a
+    # concat buffer at a channel offset
+    xw = _rand_bf16(3, 9, 130, 160, seed=43).to(DEV)
+    xs = xw[..., 32:160]
+    w2 = _rand_bf16(256, 1, 1, 128, scale=0.09, seed=44)
+    r1 = _rand_bf16(3, 9, 130, 256, seed=45)
+    ref = C.conv2d_nhwc_reference(xs.cpu(), w2, None, act="relu", res=r1, res_mode=C.RES_SAME, out_dtype=torch.float32)
+    cat = torch.zeros(3, 9, 130, 328, dtype=torch.bfloat16, device=DEV)
+    C.conv2d_nhwc(xs, w2.to(DEV), None, act="relu", res=r1.to(DEV), res_mode=C.RES_SAME, out=cat, out_coff=64, cfg=9100)
+    _close(cat[..., 64:320], ref)
+    assert cat[..., :64].abs().max().item() == 0 and cat[..., 320:].abs().max().item() == 0
+    # large enough for several tiles per workgroup; the automatic choice takes the same kernel from 32 k pixels up
+    x3 = _rand_bf16(1, 300, 400, 64, seed=46).to(DEV)
+    r3 = _rand_bf16(1, 150, 200, 256, seed=47).to(DEV)
+    forced = C.conv2d_nhwc(x3, w.to(DEV), b.to(DEV), res=r3, res_mode=C.RES_UP2, cfg=9100)
+    auto = C.conv2d_nhwc(x3, w.to(DEV), b.to(DEV), res=r3, res_mode=C.RES_UP2)
+    generic = C.conv2d_nhwc(x3, w.to(DEV), b.to(DEV), res=r3, res_mode=C.RES_UP2, cfg=3900)
+    assert torch.equal(forced, auto)
+    _close(forced, generic.float().cpu())
+    with pytest.raises(Exception):
+        C.conv2d_nhwc(x3, _rand_bf16(128, 1, 1, 64, seed=48).to(DEV), None, cfg=9100)
+
+
 def test_conv_store_modes():
     x = _rand_bf16(2, 10, 14, 64, seed=12)
     # pixel shuffle (deconv 2x2 s2): Cout = 4 * 64
@@ -298,6 +331,47 @@ def test_db_postprocess_oriented_boxes_for_slanted_lines():
         L, T = (row[2] - row[0]), (row[3] - row[1])
         assert abs(L / 2.5 - (t[2] + 2 * d)) < 4.5 and abs(T / 2.6 - (t[3] + 2 * d)) < 3.5, (L, T, t, d)
         assert abs(0.5 * (row[0] + row[2]) / 2.5 - t[0]) < 1.5 and abs(0.5 * (row[1] + row[3]) / 2.6 - t[1]) < 1.5
+
+
+def test_db_postprocess_page_skew_consensus_for_short_lines():
+    """Every wide component votes for the page's skew; short lines, whose own axis is noisy, take the consensus, and
+    a long line that disagrees with it by more than 3 degrees keeps its own angle."""
+    from PIL import Image, ImageDraw
+
+    from distributed_llms_amd.train.page_trainer import rect_corners
+
+    H, W, skew = 400, 480, np.deg2rad(2.0)
+    rows = [[240, 30 + 28 * i, 380 - 10 * (i % 3), 12, skew] for i in range(9)]          # body lines
+    rows += [[90, 300, 52, 12, skew], [300, 300, 40, 11, skew], [200, 330, 60, 12, skew]]   # short last lines
+    rows += [[240, 372, 400, 12, np.deg2rad(-6.0)]]                                          # a turned caption
+    rects = np.array(rows, dtype=np.float64)
+    im = Image.new("L", (W, H), 0)
+    d = ImageDraw.Draw(im)
+    for q in rect_corners(rects):
+        d.polygon([(float(x), float(y)) for x, y in q], fill=1)
+    m = torch.from_numpy(np.asarray(im, dtype=np.uint8).copy())
+    g = torch.Generator().manual_seed(11)
+    prob = torch.rand(H, W, generator=g) * 0.2
+    prob[m > 0] = 0.75 + 0.2 * torch.rand(int(m.sum()), generator=g)
+    prob = prob.to(torch.bfloat16)[None]
+    mask = (prob.float() > 0.3).to(torch.uint8)
+    cfg = dbpost.DBPostConfig(unclip_ratio=1.5)
+    ref = dbpost.db_postprocess_reference(prob, mask, cfg, None)[0]
+    ws = dbpost.DBPostWorkspace(1, H, W, cfg, torch.device(DEV))
+    bx, nb = dbpost.db_postprocess_gpu(prob.to(DEV), mask.to(DEV), ws, None)
+    out = bx[0, : int(nb[0])].cpu().numpy()
+    assert out.shape == ref.shape == (len(rows), 8)
+    key = lambda a: np.lexsort((a[:, 0], np.round(a[:, 1])))      # noqa: E731
+    o, r = out[key(out)], ref[key(ref)]
+    np.testing.assert_allclose(o[:, :4], r[:, :4], rtol=1e-5, atol=2e-2)
+    np.testing.assert_allclose(o[:, 6], r[:, 6], atol=2e-5)
+    page = float(ws.page_angle[0])
+    assert abs(page - skew) < np.deg2rad(0.15), np.rad2deg(page)
+    cy = 0.5 * (out[:, 1] + out[:, 3])
+    body = out[cy < 350]
+    assert len(body) == 12 and np.all(body[:, 6] == body[0, 6]) and abs(body[0, 6] - page) < 1e-6    # one angle for the page
+    caption = out[cy >= 350]
+    assert len(caption) == 1 and abs(caption[0, 6] - np.deg2rad(-6.0)) < np.deg2rad(0.3)
 
 
 def test_resample_affine_crop_of_slanted_lines():
