@@ -63,7 +63,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pages-per-doc", type=int, default=100)
     ap.add_argument("--distinct-pages", type=int, default=10, help="distinct rendered pages cycled through a document")
-    ap.add_argument("--batch-pages", type=int, default=25)
+    ap.add_argument("--batch-pages", type=int, default=36,
+                    help="largest page batch; a document is cut into the fewest equal batches below it (100 pages: 34 + 33 + 33)")
     ap.add_argument("--input", choices=["pdf", "raster"], default="pdf",
                     help="pdf: timed region starts from PDF bytes (parse + image decode); raster: decoded u8 pages")
     ap.add_argument("--codec", choices=["jpeg", "flate"], default="jpeg")

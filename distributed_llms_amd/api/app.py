@@ -24,6 +24,7 @@ import hashlib
 import json
 import logging
 import os
+import sys
 import traceback
 from contextlib import asynccontextmanager
 from typing import Optional
@@ -116,6 +117,8 @@ def create_app(settings: Optional[Settings] = None, status: Optional[StatusStore
     @asynccontextmanager
     async def lifespan(app: FastAPI):
         # ---- startup (ocr_service.py:132-163): connect, ping, indexes; errors are logged, not fatal
+        if getattr(settings, "gil_switch_ms", 0) > 0:
+            sys.setswitchinterval(settings.gil_switch_ms / 1000.0)
         try:
             if state["status"] is None or state["results"] is None:
                 st, rs = make_stores(settings)

@@ -112,8 +112,11 @@ class Settings:
     # --- engine -----------------------------------------------------------------
     num_gpus: int = -1               # -1: all visible; 0: CPU engine
     gpu_ids: Optional[str] = None    # "2,3": the devices this process drives (multi-front-end deployments)
-    max_batch_pages: int = 32
+    max_batch_pages: int = 36
     max_wait_ms: float = 20.0
+    # CPython hands the GIL over every `switch interval`; at the default 5 ms the engine thread (hundreds of kernel
+    # launches per batch) waits that long every time the HTTP thread holds it, which dominates small-batch latency
+    gil_switch_ms: float = 0.5
     det_limit_side: int = 1344
     recognizer: str = "crnn"         # crnn | trocr
     dtype: str = "bf16"
@@ -146,8 +149,9 @@ class Settings:
             output_dir=e.get("OCR_OUTPUT_DIR", "output"),
             num_gpus=_get_int(e, "OCR_NUM_GPUS", -1),
             gpu_ids=e.get("OCR_GPU_IDS") or None,
-            max_batch_pages=_get_int(e, "OCR_MAX_BATCH_PAGES", 32),
+            max_batch_pages=_get_int(e, "OCR_MAX_BATCH_PAGES", 36),
             max_wait_ms=_get_float(e, "OCR_MAX_WAIT_MS", 20.0),
+            gil_switch_ms=_get_float(e, "OCR_GIL_SWITCH_MS", 0.5),
             det_limit_side=_get_int(e, "OCR_DET_LIMIT_SIDE", 1344),
             recognizer=e.get("OCR_RECOGNIZER", "crnn"),
             dtype=e.get("OCR_DTYPE", "bf16"),

@@ -38,12 +38,14 @@ def _now() -> str:
 class JobManager:
     def __init__(self, status: StatusStore, results: ResultStore, errors: ErrorSink, extractor,
                  node_id: str = "", deadline_s: float = 600.0, io_threads: int = IO_THREADS,
-                 extract_threads: int = 8):
+                 extract_threads: int = 64):
         self.status, self.results, self.errors, self.extractor = status, results, errors, extractor
         self.node_id = node_id
         self.deadline_s = deadline_s
         self.io_pool = ThreadPoolExecutor(max_workers=io_threads, thread_name_prefix="dlamd-io")
-        # extraction calls block on the GPU workers; they get their own pool so I/O never queues behind them
+        # extraction calls block on the GPU workers; they get their own pool so I/O never queues behind them, and
+        # enough threads that every concurrent upload has its pages in the batcher at the same time (with 8, a burst
+        # of 32 four-page scans reached the engine as 8-page batches)
         self.extract_pool = ThreadPoolExecutor(max_workers=extract_threads, thread_name_prefix="dlamd-extract")
         self.tasks: Set[asyncio.Task] = set()
 

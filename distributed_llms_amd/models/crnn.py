@@ -140,11 +140,21 @@ class CRNN(nn.Module):
         return ctc_ops.ctc_greedy_decode(logits, lens, blank=0)
 
     @torch.no_grad()
-    def infer_ragged(self, xs: List[torch.Tensor], lay: "lstm_ops.RaggedLayout"
+    def first_conv_packed(self):
+        """(weight [C1,3,3,8] bf16, bias f32, activation, stride, padding) of the first convolution with BN folded:
+        what ``ops.resample.resample_stem_items_gpu`` needs to produce its output straight from the page rasters."""
+        c = self.convs[0]
+        if c._packed is None:
+            c.prepare()
+        return c._packed + (c.act, c.stride, c.padding)
+
+    @torch.no_grad()
+    def infer_ragged(self, xs: List[torch.Tensor], lay: "lstm_ops.RaggedLayout", first_conv_done: bool = False
                      ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """Recognise crops of several width buckets in one pass.
 
-        xs[b]: [N_b, 48, W_b, 8] bf16.  The conv stack runs per bucket (it needs a uniform width) and
+        xs[b]: [N_b, 48, W_b, 8] bf16 (or, with ``first_conv_done``, the first convolution's output
+        [N_b, 24, W_b / 2, C1] from the fused resample kernel).  The conv stack runs per bucket (it needs a uniform width) and
         writes its [N_b, T_b, C] features straight into one packed [R, C] row matrix; everything after
         it - both LSTM layers (input GEMM + ONE persistent recurrent launch each), the classifier GEMM
         and the CTC decode - runs once over all buckets, so the sequential recurrence sees every crop
@@ -158,9 +168,9 @@ class CRNN(nn.Module):
         r0 = 0
         for x in xs:
             y = x
-            for c in self.convs[:-1]:
+            for c in self.convs[1:-1] if first_conv_done else self.convs[:-1]:
                 y = c.infer(y)
-            N, T = x.shape[0], x.shape[2] // 4
+            N, T = x.shape[0], x.shape[2] // (2 if first_conv_done else 4)
             self.convs[-1].infer(y, out=feat[r0 : r0 + N * T].view(N, 1, T, C6))
             r0 += N * T
         assert r0 == lay.rows

@@ -109,7 +109,22 @@ class DBNet(nn.Module):
         [B,H/4,W/4,8] bf16 (channel 0 = figure logit, channel 1 = formula logit)."""
         B, H, W, _ = x.shape
         assert H % 32 == 0 and W % 32 == 0, "detector input must be a multiple of 32"
-        y = self.stem3.infer(self.stem2.infer(self.stem1.infer(x)))
+        return self.infer_after_stem1(self.stem1.infer(x), concat_buf, with_figures)
+
+    def stem1_packed(self) -> Tuple[torch.Tensor, torch.Tensor, str]:
+        """(weight [32,3,3,8] bf16, bias f32, activation) of the first convolution with BN folded - what
+        ``ops.resample.resample_stem_items_gpu`` needs to produce ``stem1``'s output straight from the page rasters."""
+        if self.stem1._packed is None:
+            self.stem1.prepare()
+        return self.stem1._packed + (self.stem1.act,)
+
+    @torch.no_grad()
+    def infer_after_stem1(self, y1: torch.Tensor, concat_buf: Optional[torch.Tensor] = None, with_figures: bool = False):
+        """``infer`` from the first convolution's output [B,H/2,W/2,32] on."""
+        B, H, W = y1.shape[0], 2 * y1.shape[1], 2 * y1.shape[2]
+        assert H % 32 == 0 and W % 32 == 0, "detector input must be a multiple of 32"
+        x = y1
+        y = self.stem3.infer(self.stem2.infer(y1))
         feats = []
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in layer:

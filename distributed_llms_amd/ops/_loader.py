@@ -82,6 +82,7 @@ def _declare(l: ctypes.CDLL) -> None:
     sig("dlamd_gemm8", [vp, vp, vp, vp, vp] + [i] * 18 + [vp])
     sig("dlamd_db_head_fused", [vp, vp, vp, vp, vp, vp, vp, i, i, i, f, vp])
     sig("dlamd_resample", [vp, i, vp, i, i, f, f, f, f, f, f, vp])
+    sig("dlamd_resample_stem", [vp, i, i, i, f, f, f, f, f, f, vp, vp, vp, i, i, vp])
     sig("dlamd_db_postprocess", [vp] * 10 + [i, i, i, i, i, f, f, i, f, vp, vp, vp])
     sig("dlamd_row_argmax", [vp, i, vp, vp, ll, i, ll, vp])
     sig("dlamd_ctc_collapse", [vp, vp, vp, vp, vp, vp, vp, i, i, i, vp])
@@ -99,6 +100,7 @@ def _declare(l: ctypes.CDLL) -> None:
     sig("dlamd_jpeg_sync", [vp, i, i, vp])
     sig("dlamd_jpeg_sync_decode", [vp, i, i, vp])
     sig("dlamd_jpeg_sync_finish", [vp, vp, i, ll, ll, vp])
+    sig("dlamd_row_cumsum_i32", [vp, vp, vp, ll, i, i, i, vp])
     sig("dlamd_lstm_train_fwd", [vp, vp, vp, vp, vp, vp, i, i, i, i, vp])
     sig("dlamd_lstm_train_bwd", [vp, vp, vp, vp, vp, vp, i, i, i, i, vp])
     sig("dlamd_dar_create", [i, i, ll, i, vp])

@@ -23,6 +23,7 @@ import torch
 
 from ..pdf.reader import JPEG_TABLES_BYTES, JpegScan
 from . import _loader
+from .scan import row_cumsum_i32
 
 DESC_DTYPE = np.dtype(
     [
@@ -133,10 +134,9 @@ def _decode_self_synchronising(streams: Sequence[np.ndarray], scans: Sequence[Jp
     dev.copy_(host, non_blocking=True)
     l, vp = _loader.lib(), _loader.ctypes.c_void_p
     _loader.check(l.dlamd_jpeg_sync(vp(base + desc_off), n, max_sub, _loader.stream_ptr()), "dlamd_jpeg_sync")
-    torch.cumsum(sub[1], dim=1, dtype=torch.int32, out=sub[2])
-    sub[2].sub_(sub[1])
+    row_cumsum_i32(sub[1], sub[2], exclusive=True)
     _loader.check(l.dlamd_jpeg_sync_decode(vp(base + desc_off), n, max_sub, _loader.stream_ptr()), "dlamd_jpeg_sync_decode")
-    torch.cumsum(dc[0], dim=1, dtype=torch.int32, out=dc[1])
+    row_cumsum_i32(dc[0], dc[1])
     _loader.check(l.dlamd_jpeg_sync_finish(vp(base + desc_off), vp(base + ptr_off), n, max_luma, max(w * h for w, h in geo),
                                            _loader.stream_ptr()), "dlamd_jpeg_sync_finish")
     res = []

@@ -207,6 +207,34 @@ def resample_items_gpu(
     return out
 
 
+def stem_serves(w: torch.Tensor, stride, padding) -> bool:
+    """Whether ``resample_stem_items_gpu`` can stand in for resample + this first convolution."""
+    return (w.dim() == 4 and tuple(w.shape[1:]) == (3, 3, 8) and w.shape[0] in (32, 64) and tuple(stride) == (2, 2)
+            and tuple(padding) == (1, 1))
+
+
+def resample_stem_items_gpu(
+    items_dev: torch.Tensor, n: int, Hd: int, Wd: int, mean, std, w: torch.Tensor, bias: Optional[torch.Tensor],
+    act: str = "relu",
+) -> torch.Tensor:
+    """Resample fused with the first convolution (3 x 3, stride 2, pad 1; ``w``: [Cout, 3, 3, 8] bf16 with BN folded,
+    Cout 32 or 64): -> [n, (Hd - 1) // 2 + 1, (Wd - 1) // 2 + 1, Cout] bf16 without ever writing the [n, Hd, Wd, 8]
+    tensor.  Same arithmetic as ``resample_items_gpu`` followed by ``conv2d_nhwc`` (the resampled value is rounded to
+    bf16 before it is multiplied)."""
+    from .conv import ACT
+
+    assert w.dtype == torch.bfloat16 and w.is_contiguous() and stem_serves(w, (2, 2), (1, 1))
+    cout = w.shape[0]
+    assert bias is None or (bias.dtype == torch.float32 and bias.numel() >= cout and bias.is_contiguous())
+    out = torch.empty((n, (Hd - 1) // 2 + 1, (Wd - 1) // 2 + 1, cout), dtype=torch.bfloat16, device=items_dev.device)
+    rc = _loader.lib().dlamd_resample_stem(
+        _loader.ptr(items_dev), n, Hd, Wd, float(mean[0]), float(mean[1]), float(mean[2]),
+        1.0 / std[0], 1.0 / std[1], 1.0 / std[2], _loader.ptr(w), _loader.ptr(bias), _loader.ptr(out), cout, ACT[act],
+        _loader.stream_ptr())
+    _loader.check(rc, "dlamd_resample_stem")
+    return out
+
+
 def resample_regions(
     regions: Sequence[Region], Hd: int, Wd: int, mean=IMAGENET_MEAN, std=IMAGENET_STD,
     out: Optional[torch.Tensor] = None,

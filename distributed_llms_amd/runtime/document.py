@@ -29,7 +29,7 @@ import torch
 from ..ops import jpeg as jpeg_ops
 from ..pdf import reader
 from . import layout
-from .engine import Figure, OcrEngine, PageImage, PageResult, StageTimer, TextLine, _to_gray
+from .engine import Figure, OcrEngine, PageImage, PageResult, StageTimer, TextLine, _to_gray, balanced_chunks
 
 
 class ExtractionError(RuntimeError):
@@ -239,8 +239,7 @@ class DocumentPipeline:
         return PageImage(t, doc_id, i, prior)
 
     def _page_batches(self, doc, page_ids, doc_id, priors, skipped: List[int]) -> Iterator[List[PageImage]]:
-        B = self.engine.cfg.max_batch_pages
-        chunks = [page_ids[k : k + B] for k in range(0, len(page_ids), B)]
+        chunks = [page_ids[a:b] for a, b in balanced_chunks(len(page_ids), self.engine.cfg.max_batch_pages)]
         futs: List[List[Future]] = []
 
         def submit(c):

@@ -112,7 +112,7 @@ class EngineConfig:
     rec_width_quantum: int = 256
     rec_max_width: int = 2560
     rec_max_batch: int = 2048
-    max_batch_pages: int = 32
+    max_batch_pages: int = 36
     max_lines_per_page: int = 1024
     min_line_px: int = 6
     vertical_ratio: float = 1.5
@@ -179,6 +179,23 @@ def deskewed_boxes(b4: np.ndarray, angles: np.ndarray, page_hw: Tuple[int, int])
     rx, ry = cx * c - cy * s_ + 0.5 * W, cx * s_ + cy * c + 0.5 * H
     hw, hh = 0.5 * (b4[:, 2] - b4[:, 0]), 0.5 * (b4[:, 3] - b4[:, 1])
     return np.stack([rx - hw, ry - hh, rx + hw, ry + hh], 1).astype(np.float32), a
+
+
+def balanced_chunks(n: int, limit: int) -> List[Tuple[int, int]]:
+    """[start, end) ranges that cut ``n`` items into the fewest batches of at most ``limit``, all of (nearly) the same
+    size: 100 pages at a limit of 36 are 34 + 33 + 33, not 36 + 36 + 28.  A short tail batch runs every layer of both
+    models at a worse tile fill for the same launch count (measured on 100-page scans: 25 x 4 890 pages/s, 40 + 40 +
+    20 845, 34 + 33 + 33 920)."""
+    if n <= 0:
+        return []
+    nb = -(-n // max(1, limit))
+    base, extra = divmod(n, nb)
+    out, a = [], 0
+    for k in range(nb):
+        b = a + base + (1 if k < extra else 0)
+        out.append((a, b))
+        a = b
+    return out
 
 
 class OcrEngine:
@@ -259,19 +276,27 @@ class OcrEngine:
                     img = torch.rot90(img, k=-(p.rotation // 90), dims=(0, 1)).contiguous()
                     srcs[i] = img
                 regions.append(rs.Region(img, (0.0, 0.0, float(img.shape[1]), float(img.shape[0])), oh, ow))
-            x = self._resample(regions, Hd, Wd, rs.IMAGENET_MEAN, rs.IMAGENET_STD)
             figs = cfg.detect_figures and hasattr(self.det, "fig_head")
             fprob = fmask = qprob = qmask = None
             frm = figs and cfg.detect_formulas
+            det_infer = self.det.infer
+            if self.on_gpu and hasattr(self.det, "stem1_packed") and rs.stem_serves(self.det.stem1_packed()[0], (2, 2), (1, 1)):
+                # page resample fused with the detector's first convolution: the [B, Hd, Wd, 8] tensor is never written
+                w1, b1, act1 = self.det.stem1_packed()
+                x = rs.resample_stem_items_gpu(self._upload_items(regions), len(regions), Hd, Wd, rs.IMAGENET_MEAN,
+                                               rs.IMAGENET_STD, w1, b1, act1)
+                det_infer = self.det.infer_after_stem1
+            else:
+                x = self._resample(regions, Hd, Wd, rs.IMAGENET_MEAN, rs.IMAGENET_STD)
             if figs:
-                prob, mask, fig = self.det.infer(x, with_figures=True)
+                prob, mask, fig = det_infer(x, with_figures=True)
                 fl = fig[..., 0].float()
                 fprob, fmask = torch.sigmoid(fl).to(torch.bfloat16).contiguous(), (fl > 0).to(torch.uint8).contiguous()
                 if frm:
                     ql = fig[..., 1].float()
                     qprob, qmask = torch.sigmoid(ql).to(torch.bfloat16).contiguous(), (ql > 0).to(torch.uint8).contiguous()
             else:
-                prob, mask = self.det.infer(x)
+                prob, mask = det_infer(x)
             scale = torch.tensor([[p.hw[1] / g[1], p.hw[0] / g[0]] for p, g in zip(pages, geo)],
                                  dtype=torch.float32)
             valid = torch.tensor([[g[1], g[0]] for g in geo], dtype=torch.int32)
@@ -331,14 +356,15 @@ class OcrEngine:
             db.srcs = srcs
         return db
 
+    def _upload_items(self, regions) -> torch.Tensor:
+        items = rs.pack_items(regions)
+        host = torch.from_numpy(items.view(np.uint8).reshape(-1)).pin_memory()
+        return host.to(self.device, non_blocking=True)
+
     def _resample(self, regions, Hd, Wd, mean, std) -> torch.Tensor:
         if not self.on_gpu:
             return rs.resample_regions(regions, Hd, Wd, mean, std)
-        items = rs.pack_items(regions)
-        host = torch.from_numpy(items.view(np.uint8).reshape(-1)).pin_memory()
-        dev = host.to(self.device, non_blocking=True)
-        out = rs.resample_items_gpu(dev, len(regions), Hd, Wd, mean, std)
-        return out
+        return rs.resample_items_gpu(self._upload_items(regions), len(regions), Hd, Wd, mean, std)
 
     def _det_boxes(self, db: _DetBatch) -> List[Tuple[np.ndarray, np.ndarray]]:
         """Wait for the detector of this batch.  Per page: (lines [n, 8] = x0, y0, x1, y1, score, block, angle, kind
@@ -675,12 +701,19 @@ class OcrEngine:
         tcap_d = dev[o : o + 4 * n].view(torch.int32); o += 4 * n
         perm_d = dev[o : o + 4 * n].view(torch.int32)
         xs, c0 = [], 0
+        # crop resample fused with the recogniser's first convolution where the model offers it
+        first = self.rec.first_conv_packed() if hasattr(self.rec, "first_conv_packed") else None
+        fused = first is not None and rs.stem_serves(first[0], first[3], first[4])
         for wb, sel in buckets:
-            xs.append(rs.resample_items_gpu(items_d[56 * c0 : 56 * (c0 + sel.size)], sel.size, cfg.rec_height, wb,
-                                            rs.HALF_MEAN, rs.HALF_STD))
+            it = items_d[56 * c0 : 56 * (c0 + sel.size)]
+            if fused:
+                xs.append(rs.resample_stem_items_gpu(it, sel.size, cfg.rec_height, wb, rs.HALF_MEAN, rs.HALF_STD,
+                                                     first[0], first[1], first[2]))
+            else:
+                xs.append(rs.resample_items_gpu(it, sel.size, cfg.rec_height, wb, rs.HALF_MEAN, rs.HALF_STD))
             c0 += sel.size
         lay = lstm_ops.RaggedLayout(row_off_d, tcap_d, lens_d, perm_d, rows, tmax)
-        ids, ln, conf = self.rec.infer_ragged(xs, lay)
+        ids, ln, conf = self.rec.infer_ragged(xs, lay, first_conv_done=fused)
         h_ids = torch.empty((n, tmax), dtype=torch.int32, pin_memory=True)
         h_ln = torch.empty((n,), dtype=torch.int32, pin_memory=True)
         h_cf = torch.empty((n,), dtype=torch.float32, pin_memory=True)
@@ -851,9 +884,8 @@ class OcrEngine:
         return r
 
     def process_pages(self, pages: Sequence[PageImage]) -> List[PageResult]:
-        B = self.cfg.max_batch_pages
         out: List[PageResult] = []
-        for res in self.process_batches(pages[i : i + B] for i in range(0, len(pages), B)):
+        for res in self.process_batches(pages[a:b] for a, b in balanced_chunks(len(pages), self.cfg.max_batch_pages)):
             out.extend(res)
         return out
 

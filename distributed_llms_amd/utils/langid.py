@@ -15,7 +15,10 @@ Two stages, no model files:
 from __future__ import annotations
 
 import re
+from collections import Counter
 from typing import Dict, Tuple
+
+import numpy as np
 
 _SCRIPTS = (
     ("latin", ((0x41, 0x5A), (0x61, 0x7A), (0xC0, 0x24F))),
@@ -56,22 +59,33 @@ _SETS = {k: frozenset(v.split()) for k, v in _WORDS.items()}
 _TOKEN = re.compile(r"[^\W\d_]+", re.UNICODE)
 
 
+_ALPHA = re.compile(r"[^\W\d_]+", re.UNICODE)
+
+
 def script_shares(text: str) -> Dict[str, float]:
-    counts: Dict[str, int] = {}
-    n = 0
-    for ch in text:
-        if not ch.isalpha():
-            continue
-        o = ord(ch)
-        n += 1
-        for name, ranges in _SCRIPTS:
-            if any(lo <= o <= hi for lo, hi in ranges):
-                counts[name] = counts.get(name, 0) + 1
-                break
-    return {k: v / n for k, v in counts.items()} if n else {}
+    """Share of the letters of ``text`` per script.  Runs at C speed (one regex pass to keep the letters, numpy range
+    tests on their code points): a per-character Python loop held the interpreter lock for ~2.5 us per character,
+    50 ms for a 20 k-character document, in a service whose event loop shares that lock."""
+    letters = "".join(_ALPHA.findall(text))
+    n = len(letters)
+    if n == 0:
+        return {}
+    cp = np.frombuffer(letters.encode("utf-32-le", "surrogatepass"), dtype=np.uint32)
+    free = np.ones(n, dtype=bool)            # a letter counts for the first script whose ranges hold it
+    out: Dict[str, float] = {}
+    for name, ranges in _SCRIPTS:
+        m = np.zeros(n, dtype=bool)
+        for lo, hi in ranges:
+            m |= (cp >= lo) & (cp <= hi)
+        m &= free
+        c = int(m.sum())
+        if c:
+            out[name] = c / n
+            free &= ~m
+    return out
 
 
-def detect(text: str, max_chars: int = 20000) -> Tuple[str, float]:
+def detect(text: str, max_chars: int = 8000) -> Tuple[str, float]:
     """-> (language or script code, confidence in [0, 1]).  ``und`` when there is too little text to tell."""
     text = text[:max_chars]
     shares = script_shares(text)
@@ -87,8 +101,9 @@ def detect(text: str, max_chars: int = 20000) -> Tuple[str, float]:
         return "und", 0.0
     scores: Dict[str, float] = {}
     low = text.lower()
+    seen = Counter(toks)
     for lang, words in _SETS.items():
-        hits = sum(1 for t in toks if t in words)
+        hits = sum(seen[w] for w in words if w in seen)
         bonus = sum(low.count(c) for c in _LETTERS.get(lang, ""))
         scores[lang] = hits + 0.5 * min(bonus, 0.2 * len(toks))
     best = max(scores, key=scores.get)

@@ -419,3 +419,15 @@ def test_db_head_fused_matches_the_two_deconv_launches(shape):
     with torch.no_grad():
         want = net.head3(net.head2(h.float().permute(0, 3, 1, 2)))[:, 0]
     assert float((p_f.float() - want).abs().max()) < 0.03
+
+
+def test_row_cumsum_matches_torch_for_ragged_lengths():
+    from distributed_llms_amd.ops.scan import row_cumsum_i32
+
+    g = torch.Generator().manual_seed(3)
+    for rows, n in ((1, 1), (3, 1023), (5, 1024), (4, 1025), (36, 136_000), (2, 300_001)):
+        x = torch.randint(-2000, 2000, (rows, n), dtype=torch.int32, generator=g).to(DEV)
+        want = torch.cumsum(x, dim=1, dtype=torch.int32)
+        out = torch.empty_like(x)
+        assert torch.equal(row_cumsum_i32(x, out), want), (rows, n)
+        assert torch.equal(row_cumsum_i32(x, out, exclusive=True), want - x), (rows, n)

@@ -398,6 +398,38 @@ def test_resample_affine_crop_of_slanted_lines():
     assert (flat[0].float() - out[0].float()).abs().mean().item() > 0.02
 
 
+def test_resample_fused_with_first_conv_matches_the_two_step_path():
+    """resample + 3x3 stride-2 conv in one kernel (gray and RGB sources, box filter / bilinear / affine / rotated
+    regions, odd sizes, both channel counts) against the resample kernel followed by the conv kernel."""
+    g = torch.Generator().manual_seed(9)
+    page = torch.randint(0, 256, (400, 600), dtype=torch.uint8, generator=g)
+    page = torch.nn.functional.avg_pool2d(page[None, None].float(), 3, 1, 1)[0, 0].to(torch.uint8)
+    rgb = torch.randint(0, 256, (150, 260, 3), dtype=torch.uint8, generator=g)
+    regs = [
+        resample.Region(page, (0.0, 0.0, 600.0, 400.0), 150, 230),                 # shrink 2.6x
+        resample.Region(page, (50.0, 100.0, 550.0, 160.0), 48, 400, 0, 0.06),      # slanted line
+        resample.Region(page, (100.0, 50.0, 300.0, 70.0), 48, 470),                # enlarge
+        resample.Region(rgb, (20.0, 30.0, 250.0, 140.0), 90, 190),                 # RGB source
+        resample.Region(page, (300.0, 40.0, 340.0, 380.0), 48, 408, 1),            # turned by 90 degrees
+        resample.Region(page, (10.0, 10.0, 590.0, 390.0), 151, 471),               # fills the bucket, shrink 1.2 / 2.5
+    ]
+    dregs = [resample.Region(r.image.to(DEV), r.box, r.out_h, r.out_w, r.rot, r.angle) for r in regs]
+    items = torch.from_numpy(resample.pack_items(dregs).view(np.uint8).copy()).to(DEV)
+    for (Hd, Wd), cout, mean, std, act in (((151, 471), 32, resample.IMAGENET_MEAN, resample.IMAGENET_STD, "relu"),
+                                           ((152, 480), 64, resample.HALF_MEAN, resample.HALF_STD, "hardswish")):
+        w = torch.zeros(cout, 3, 3, 8)
+        w[..., :3] = torch.randn(cout, 3, 3, 3, generator=g) * 0.3
+        w = w.to(torch.bfloat16).to(DEV)
+        b = (torch.randn(cout, generator=g) * 0.2).to(DEV)
+        x = resample.resample_items_gpu(items, len(regs), Hd, Wd, mean, std)
+        want = C.conv2d_nhwc(x, w, b, stride=2, padding=1, act=act)
+        got = resample.resample_stem_items_gpu(items, len(regs), Hd, Wd, mean, std, w, b, act)
+        assert got.shape == want.shape == (len(regs), (Hd - 1) // 2 + 1, (Wd - 1) // 2 + 1, cout)
+        _close(got, want, rtol=1e-2, atol=1e-2)
+        ref = C.conv2d_nhwc_reference(x.cpu(), w.cpu(), b.cpu(), stride=2, padding=1, act=act, out_dtype=torch.float32)
+        _close(got, ref, rtol=1e-2, atol=2e-2)
+
+
 def test_db_postprocess_random_noise_components():
     g = torch.Generator().manual_seed(1)
     prob = torch.rand(2, 96, 128, generator=g).to(torch.bfloat16)

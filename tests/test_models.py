@@ -132,3 +132,17 @@ def test_crnn_ragged_equals_per_bucket_cpu():
 @pytest.mark.gpu
 def test_crnn_ragged_equals_per_bucket_gpu():
     _ragged_case("cuda")
+
+
+def test_balanced_chunks_cut_a_document_into_equal_batches():
+    from distributed_llms_amd.runtime.engine import balanced_chunks
+
+    assert balanced_chunks(100, 36) == [(0, 34), (34, 67), (67, 100)]
+    assert balanced_chunks(100, 25) == [(0, 25), (25, 50), (50, 75), (75, 100)]
+    assert balanced_chunks(5, 36) == [(0, 5)] and balanced_chunks(0, 36) == []
+    assert balanced_chunks(37, 36) == [(0, 19), (19, 37)]
+    for n in range(1, 200):
+        ch = balanced_chunks(n, 7)
+        sizes = [b - a for a, b in ch]
+        assert ch[0][0] == 0 and ch[-1][1] == n and all(ch[i][1] == ch[i + 1][0] for i in range(len(ch) - 1))
+        assert max(sizes) <= 7 and max(sizes) - min(sizes) <= 1 and len(ch) == -(-n // 7)
