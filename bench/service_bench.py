@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--text-docs", type=int, default=200)
     ap.add_argument("--scan-pages", type=int, default=100)
     ap.add_argument("--scan-docs", type=int, default=4)
+    ap.add_argument("--scan-clients", type=int, default=3, help="concurrent clients of the sustained 100-page phase (0: skip)")
+    ap.add_argument("--scan-rounds", type=int, default=4, help="documents each of them uploads, one after another")
     ap.add_argument("--burst-docs", type=int, default=32)
     ap.add_argument("--burst-pages", type=int, default=4)
     ap.add_argument("--burst-rounds", type=int, default=6, help="documents each concurrent client submits, one after another")
@@ -136,6 +138,27 @@ def main():
                                 "upload_s": [round(r[3], 3) for r in res], "status": res[-1][1],
                                 "pages_per_s": round(n / best, 1), "text_chars": len(got),
                                 "truth_lines_found_verbatim": round(line_hit, 4), "cer_first_page": round(cer, 5)}
+
+    # ---- config 2, sustained: several clients upload 100-page scans at the same time, so one document's upload
+    # overlaps another's recognition (a lone document pays upload + engine time back to back)
+    if args.scan_clients > 0:
+        sb = [[body_for(scan, f"cscan-{i}-{r}") for r in range(args.scan_rounds)] for i in range(args.scan_clients)]
+        slat = []
+
+        def big(i):
+            c = Client(args.port)
+            for r in range(args.scan_rounds):
+                slat.append(run_doc(c, *sb[i][r], f"cscan-{i}-{r}", poll=0.005)[0])
+
+        t0 = time.perf_counter()
+        ths = [threading.Thread(target=big, args=(i,)) for i in range(args.scan_clients)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        wall = time.perf_counter() - t0
+        out["config2_concurrent_scans"] = {"clients": args.scan_clients, "docs_per_client": args.scan_rounds, "pages_each": n,
+                                           "pages_per_s": round(args.scan_clients * args.scan_rounds * n / wall, 1),
+                                           "p50_s": round(float(np.percentile(slat, 50)), 3)}
+        del sb
 
     # ---- burst of small scans from concurrent clients
     small = synth.make_scanned_pdf([rendered[i % 10] for i in range(args.burst_pages)], codec="jpeg",

@@ -246,7 +246,9 @@ class StreamingForm:
         else:
             body = memoryview(b"".join(self.chunks))
             self.chunks = []
-        parts = _parse_view(body, self.delim, self.max_parts)
+        # the incremental scan has already found where the hashed file part ends: the final parse does not search
+        # those bytes again (a second pass over a 120 MB upload is 30-50 ms on the event loop, after the last byte)
+        parts = _parse_view(body, self.delim, self.max_parts, self._file_span if self.fixed else None)
         self._digest = None
         if self._file_span is not None:
             for f in self._hash_futs:
@@ -264,8 +266,10 @@ class StreamingForm:
         return getattr(self, "_digest", None)
 
 
-def _parse_view(body: memoryview, delim: bytes, max_parts: int) -> List[Part]:
-    """``parse_multipart`` over a memoryview; file parts keep views (no copy), form fields become bytes."""
+def _parse_view(body: memoryview, delim: bytes, max_parts: int, known_span: Optional[tuple] = None) -> List[Part]:
+    """``parse_multipart`` over a memoryview; file parts keep views (no copy), form fields become bytes.
+    ``known_span`` = (data_start, end) of a part whose closing delimiter an earlier scan has located: it is checked
+    in place instead of searched for."""
     raw = body.obj if isinstance(body.obj, (bytes, bytearray)) and len(body.obj) == len(body) else bytes(body)
     pos = raw.find(delim)
     if pos < 0:
@@ -292,7 +296,12 @@ def _parse_view(body: memoryview, delim: bytes, max_parts: int) -> List[Part]:
             k, v = line.split(b":", 1)
             headers[k.decode("latin-1").strip().lower()] = v.decode("utf-8", "replace").strip()
         data_start = hdr_end + 4
-        nxt = raw.find(b"\r\n" + delim, data_start)
+        closing = b"\r\n" + delim
+        if (known_span is not None and known_span[0] == data_start and known_span[1] >= data_start
+                and raw[known_span[1] : known_span[1] + len(closing)] == closing):
+            nxt = known_span[1]       # the first occurrence after data_start, as the incremental scan established
+        else:
+            nxt = raw.find(closing, data_start)
         if nxt < 0:
             raise MultipartError("closing boundary not found")
         disp = headers.get("content-disposition")

@@ -71,11 +71,13 @@ class DynamicBatcher:
                 self._items.pop(iid, None)
             raise RuntimeError("batcher is closed")
 
-    def pop(self, timeout_ms: float = -1.0, flush: bool = False) -> Tuple[Optional[int], List[object]]:
-        """Next batch as (shape key, payloads); (None, []) on timeout or when closed and drained."""
+    def pop(self, timeout_ms: float = -1.0, flush: bool = False, cap: int = 0) -> Tuple[Optional[int], List[object]]:
+        """Next batch as (shape key, payloads); (None, []) on timeout or when closed and drained.  ``cap`` > 0 takes
+        at most that many items (the rest of the bucket stays queued)."""
         key = ctypes.c_uint64()
+        limit = min(self.max_items, cap) if cap > 0 else self.max_items
         n = lib().dlrt_batcher_pop(self._h, 1 if flush else 0, int(timeout_ms * 1000) if timeout_ms >= 0 else -1,
-                                   self._buf, self.max_items, ctypes.byref(key))
+                                   self._buf, limit, ctypes.byref(key))
         if n <= 0:
             return None, []
         with self._mu:

@@ -15,6 +15,7 @@ thread as page batches that freely mix documents.  Results are routed back per d
 """
 from __future__ import annotations
 
+import collections
 import logging
 import threading
 import time
@@ -77,6 +78,8 @@ class EngineService:
         self._jobs: Dict[str, _Job] = {}
         self._mu = threading.Lock()
         self._seq = 0
+        self.recent_batch_sizes = collections.deque(maxlen=64)
+        self._outstanding = 0            # pages submitted and not yet handed to the engine (queued or still decoding)
         self._slots = threading.Semaphore(max_pending_pages or 8 * self.engine.cfg.max_batch_pages)
         self._closed = False
         self.batches = 0
@@ -97,6 +100,7 @@ class EngineService:
             self._seq += 1
             job = _Job(f"j{self._seq}", len(page_ids), on_progress)
             self._jobs[job.key] = job
+            self._outstanding += len(page_ids)
         if not page_ids:
             job.future.set_result({})
             self._forget(job)
@@ -129,12 +133,14 @@ class EngineService:
         finally:
             if not pushed:
                 self._slots.release()
+                with self._mu:
+                    self._outstanding -= 1
 
     # ------------------------------------------------------------------ engine thread
     def _next_batch(self, block: bool):
         if self.fault_hook is not None:
             self.fault_hook()
-        _, items = self.batcher.pop(timeout_ms=-1.0 if block else 0.0, flush=False)
+        items = self._pop_balanced(block)
         if not items:
             if self._closed and self.batcher.pending() == 0:
                 return OcrEngine.STREAM_END
@@ -149,7 +155,32 @@ class EngineService:
                     live.append(p)
         self.batches += 1
         self.pages_in_batches += len(live)
+        self.recent_batch_sizes.append(len(items))
         return live or None
+
+    def _pop_balanced(self, block: bool):
+        """Pop the next batch, sized so that the pages on their way (queued or still decoding) split into equal batches:
+        100 pages of one document at a limit of 36 leave as 34 + 33 + 33 rather than 36 + 36 + 28 (a short last batch
+        runs every layer at a worse tile fill).  A batch is taken as soon as that many pages wait; otherwise the
+        batcher's own rule applies (full bucket, or the oldest page's deadline)."""
+        B = self.batcher.max_items
+        while True:
+            with self._mu:
+                out = self._outstanding
+            cap = B
+            if out > B:
+                nb = -(-out // B)
+                cap = -(-out // nb)
+            if cap < B and self.batcher.pending() >= cap:
+                _, items = self.batcher.pop(timeout_ms=0.0, flush=True, cap=cap)
+            else:
+                _, items = self.batcher.pop(timeout_ms=(2.0 if cap < B else -1.0) if block else 0.0, flush=False, cap=cap)
+            if items:
+                with self._mu:
+                    self._outstanding -= len(items)
+                return items
+            if not block or cap >= B or (self._closed and self.batcher.pending() == 0):
+                return items
 
     def _run(self) -> None:
         while True:

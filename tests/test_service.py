@@ -52,6 +52,19 @@ def test_concurrent_documents_share_batches_and_keep_their_pages(extractor):
     assert st["mean_batch_pages"] > 1.0             # pages of different documents did share batches
 
 
+def test_a_long_document_leaves_in_equal_batches(extractor):
+    """10 pages at a limit of 4 per batch are 4 + 3 + 3, not 4 + 4 + 2."""
+    svc = extractor.service
+    assert svc.batcher.max_items == 4
+    svc.recent_batch_sizes.clear()
+    res = extractor.extract_document(_scan_pdf(10, seed0=300), "long")
+    assert len(res.pages) == 10 and svc._outstanding == 0
+    sizes = list(svc.recent_batch_sizes)
+    assert sum(sizes) == 10 and max(sizes) <= 4, sizes
+    if len(sizes) == 3:          # every page was decoded before the engine asked (a slow host may add deadline batches)
+        assert max(sizes) - min(sizes) <= 1, sizes
+
+
 def test_a_broken_document_fails_alone(extractor):
     good = _scan_pdf(2)
     res = {}
