@@ -48,6 +48,27 @@ def main():
             except Exception as e:  # noqa: BLE001
                 row[str(cfg)] = str(e)[:60]
         print(json.dumps(row), flush=True)
+    # stride-2 3x3 layers that run on the 64 x 128 direct-weight tile by default
+    for name, n, H, W, Cin, Cout in (("crnn c2 64->128 s2 24 rows", 300, 24, 960, 64, 128), ("layer2.0.c1 64->128 s2 @1/4", B, 336, 240, 64, 128),
+                                     ("layer3.0.c1 128->256 s2 @1/8", B, 168, 120, 128, 256)):
+        x = torch.randn(n, H, W, Cin, device=dev).to(torch.bfloat16)
+        w = (torch.randn(Cout, 3, 3, Cin, device=dev) * 0.02).to(torch.bfloat16)
+        b = torch.zeros(Cout, device=dev)
+        fl = 2.0 * n * (H // 2) * (W // 2) * Cout * 9 * Cin
+        row = {"layer": name, "gflop": round(fl / 1e9, 1)}
+        ref = None
+        for cfg in (0, 3064, 3264, 3464, 3428, 3128, 1128, 8256):
+            try:
+                y = C.conv2d_nhwc(x, w, b, stride=2, padding=1, act="relu", cfg=cfg)
+                if ref is None:
+                    ref = y.float()
+                else:
+                    assert (y.float() - ref).abs().max().item() < 0.1, cfg
+                ms = timed(lambda: C.conv2d_nhwc(x, w, b, stride=2, padding=1, act="relu", cfg=cfg))
+                row[str(cfg)] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1)}
+            except Exception as e:  # noqa: BLE001
+                row[str(cfg)] = str(e)[:60]
+        print(json.dumps(row), flush=True)
     # FPN laterals (1x1 into 256 channels, + nearest-2x residual): streaming kernel (9100) against the generic tiles
     for name, H, W, Cin in (("in2 64->256 @1/4 +up2", 336, 240, 64), ("in3 128->256 @1/8 +up2", 168, 120, 128)):
         x = torch.randn(B, H, W, Cin, device=dev).to(torch.bfloat16)
