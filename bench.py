@@ -92,8 +92,9 @@ def parse_args():
 
 def main_via_pool(args):
     """Product path: one front end (rank 0) + one engine worker process per GPU.  A step = N documents of
-    --pages-per-doc pages in flight at once (weak scaling: one document per GPU per step); the pool shards them over
-    the workers and its engine loops batch pages across documents."""
+    --pages-per-doc pages (weak scaling: one document per GPU per step); like the default mode's back-to-back queue,
+    the documents of all steps are submitted through 2 N client threads, so two documents per GPU are in flight and a
+    worker's engine loop batches pages across them; the pool shards documents over the workers."""
     import torch.distributed as dist
     from concurrent.futures import ThreadPoolExecutor
 
@@ -131,16 +132,16 @@ def main_via_pool(args):
         ext = PoolExtractor(pool)
         try:
             with ThreadPoolExecutor(max_workers=2 * n) as tp:
-                def step(tag):
-                    docs = list(tp.map(lambda k: ext.extract_document(pdf, f"{tag}-{k}"), range(n)))
+                def run(tag, steps):
+                    docs = list(tp.map(lambda k: ext.extract_document(pdf, f"{tag}-{k}"), range(n * steps)))
                     assert all(len(d.pages) == args.pages_per_doc for d in docs)
                     return sum(len(p.lines) for d in docs for p in d.pages)
 
-                for w in range(args.warmup):
-                    step(f"warm{w}")
+                if args.warmup:
+                    run("warm", args.warmup)
                 barrier()
                 t0 = time.perf_counter()
-                n_lines = sum(step(f"bench{k}") for k in range(args.steps))
+                n_lines = run("bench", args.steps)
                 dt = time.perf_counter() - t0
                 barrier()
             total_pages = args.steps * args.pages_per_doc * n
@@ -154,7 +155,7 @@ def main_via_pool(args):
                 "config": {"model": "DBNet-R18 + CRNN + CTC greedy", "global_batch": args.pages_per_doc * n,
                            "seq_len": 640 if use_gpu else 64, "parallelism": f"pool{n}",
                            "pages_per_step_per_gpu": args.pages_per_doc, "page_px": list(size),
-                           "documents": f"{n} in flight per step through WorkerPool (front end + one engine process per GPU, "
+                           "documents": f"{2 * n} in flight through WorkerPool (front end + one engine process per GPU, "
                                         "dynamic batching, page sharding)",
                            "lines_recognized": n_lines, "pool": {k: v for k, v in pool.describe().items() if k != "worker_stats"}},
             }
