@@ -30,7 +30,11 @@ from ..ops.conv import linear_bf16
 from .layers import ConvBNAct, prepare_all
 
 # 95 printable ASCII characters; vocabulary index 0 is the CTC blank.
-DEFAULT_CHARSET = "".join(chr(c) for c in range(32, 127))
+ASCII_CHARSET = "".join(chr(c) for c in range(32, 127))
+# Western European letters and the signs that come with them (Latin-1 plus the oe ligatures and the euro sign).  They
+# FOLLOW the ASCII classes, so a model grown from an ASCII checkpoint keeps its class indices.
+LATIN_EXTRA = ("ÀÁÂÃÄÅÆÇÈÉÊËÌÍÎÏÑÒÓÔÕÖØÙÚÛÜÝ" "àáâãäåæçèéêëìíîïñòóôõöøùúûüýÿß" "Œœ€£§°«»¿¡")
+DEFAULT_CHARSET = ASCII_CHARSET + LATIN_EXTRA
 
 
 class CRNN(nn.Module):
@@ -56,6 +60,35 @@ class CRNN(nn.Module):
         self.fc = nn.Linear(2 * hidden, self.num_classes)
         self._packed = None
         self.fused_train_lstm = hidden in (64, 128, 256)   # device tensors: HIP recurrence kernels in forward()
+
+    # ------------------------------------------------------------------ character set follows the weights
+    def set_charset(self, charset: str) -> None:
+        """Resize the classifier to ``charset``; classes shared with the current one (a common prefix) keep their rows,
+        new classes start from small random weights and a low bias."""
+        old_w, old_b = self.fc.weight.data, self.fc.bias.data
+        keep = 1
+        while keep - 1 < min(len(charset), len(self.charset)) and charset[keep - 1] == self.charset[keep - 1]:
+            keep += 1
+        self.charset = charset
+        self.num_classes = len(charset) + 1
+        self.vocab_padded = (self.num_classes + 3) // 4 * 4
+        fc = nn.Linear(old_w.shape[1], self.num_classes).to(device=old_w.device, dtype=old_w.dtype)
+        with torch.no_grad():
+            fc.weight.mul_(0.1)
+            fc.bias.fill_(-2.0)
+            k = min(keep, self.num_classes, old_w.shape[0])
+            fc.weight[:k] = old_w[:k]
+            fc.bias[:k] = old_b[:k]
+        self.fc = fc
+        self._packed = None
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """A checkpoint with fewer (or more) classes than this model reads the leading part of ``DEFAULT_CHARSET``:
+        the model takes the checkpoint's character set (weights trained on printable ASCII have 96 classifier rows)."""
+        w = state_dict.get("fc.weight")
+        if w is not None and w.shape[0] != self.fc.out_features and 1 < w.shape[0] <= len(DEFAULT_CHARSET) + 1:
+            self.set_charset(DEFAULT_CHARSET[: w.shape[0] - 1])
+        return super().load_state_dict(state_dict, strict=strict, assign=assign)
 
     @staticmethod
     def time_steps(width: int) -> int:

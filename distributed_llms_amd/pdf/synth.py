@@ -35,6 +35,22 @@ _WORDS = (
     "2024 2025 1,250.00 37% 4.5 No. 12 (a) [3] A-17 x=3 y<9 #42 $99 & / : ; ? !"
 ).split()
 
+# Western European vocabulary (German, French, Spanish, Italian, Portuguese, Scandinavian) and the signs that come
+# with it: every character of models/crnn.py::LATIN_EXTRA occurs at least once
+_WORDS_I18N = (
+    "über für können müssen Straße Größe Änderung Österreich schön während möglich natürlich Geschäft Prüfung Lösung "
+    "Verfügung zurück fünf zwölf Maß weiß heißt Ägypten Ärzte Ölpreis Übung Fuß Mädchen Bücher "
+    "été être déjà où à très après même français façon reçu élève hôtel garçon forêt naïve Noël cœur œuvre sœur août "
+    "coût crème tête École État Île Œuvre Ça Èze Êtes aiguë maïs où dû sûr L'Haÿ "
+    "año señor niño mañana español también después más está aquí cómo qué día información corazón ¿Cómo? ¡Hola! "
+    "pingüino Ñandú Óscar Úbeda Ímpar Ávila Él "
+    "perché più città è così università qualità già però lunedì caffè Àsia Ìsola Òpera Ùltimo "
+    "não são ação coração informação você português maçã pão irmã órgão avó avô Ã Õ Â Ê Î Ô Û Ë Ï Ý ý "
+    "år också är på både språk smör gå sjö kött blå Århus København fjørd smørrebrød Ørsted Ælfred æble Åland Ýmir "
+    "île âme põe âge maître dîner lições "
+    "12,50 € £30 §4 25 °C «oui» «non» 3 € § 7 90° £ 1.200,00 €"
+).split()
+
 _FONT_CACHE = {}
 
 
@@ -51,9 +67,10 @@ def font(size: int, bold: bool = False) -> ImageFont.FreeTypeFont:
     return f
 
 
-def random_text(rng: np.random.Generator, max_chars: int, min_words: int = 1) -> str:
+def random_text(rng: np.random.Generator, max_chars: int, min_words: int = 1, vocabulary: Optional[Sequence[str]] = None) -> str:
     words: List[str] = []
     n = 0
+    _WORDS = vocabulary or globals()["_WORDS"]
     while True:
         w = _WORDS[int(rng.integers(len(_WORDS)))]
         if rng.random() < 0.08:
@@ -189,10 +206,37 @@ def named_font(name: str, size: int) -> ImageFont.FreeTypeFont:
     return f
 
 
+_FONT_CMAPS = {}
+
+
+def font_code_points(name: str) -> Optional[frozenset]:
+    """Code points the font file maps to a glyph (None when the file or fontTools is missing: assume everything)."""
+    if name not in _FONT_CMAPS:
+        cps = None
+        path = font_path(name)
+        if path:
+            try:
+                from fontTools.ttLib import TTFont
+
+                cps = frozenset(TTFont(path, lazy=True).getBestCmap().keys())
+            except Exception:  # noqa: BLE001 - no fontTools / unreadable table: do not filter
+                cps = None
+        _FONT_CMAPS[name] = cps
+    return _FONT_CMAPS[name]
+
+
 def _font_safe(text: str, name: str) -> str:
+    """``text`` without the characters ``name`` cannot draw (the truth is what is on the page)."""
     if name.startswith("cm"):
-        return "".join(c for c in text if c not in _CM_UNSAFE).strip()
-    return text
+        text = "".join(c for c in text if c not in _CM_UNSAFE)
+    if not text.isascii():
+        cps = font_code_points(name)
+        if cps is not None:
+            text = "".join(c for c in text if ord(c) < 128 or ord(c) in cps)
+        if name.startswith("cm"):
+            text = "".join(c for c in text if ord(c) < 128)      # TeX encodings: only the ASCII range is what it says
+        text = " ".join(text.split())
+    return text.strip() if name.startswith("cm") else text
 
 
 def _figure_patch(rng: np.random.Generator, w: int, h: int) -> np.ndarray:
@@ -306,11 +350,13 @@ FORMULA_FONTSETS = ("cm", "stix", "dejavusans", "dejavuserif", "stixsans")
 def render_layout_page(seed: int, size: Tuple[int, int] = A4_300DPI, layout: Optional[str] = None,
                        fonts: Optional[Sequence[str]] = None, font_px: Optional[int] = None, skew: float = 0.0,
                        noise: float = 2.0, blur: float = 0.0, margin: Optional[int] = None,
-                       header_footer: Optional[bool] = None, formulas: float = 0.0) -> Tuple[np.ndarray, PageTruth]:
+                       header_footer: Optional[bool] = None, formulas: float = 0.0,
+                       i18n: float = 0.0) -> Tuple[np.ndarray, PageTruth]:
     """A synthetic scanned page with a real layout: running header / footer, an optional full-width title, one or
     two columns of paragraphs, optionally a figure with its caption inside a column; one font per page drawn from
     ``fonts``; optional skew (degrees), blur and sensor noise.  ``formulas`` > 0: that share of the paragraph breaks
-    carries a centred display formula (``random_formula`` through mathtext).  The truth lists the lines in READING
+    carries a centred display formula (``random_formula`` through mathtext).  ``i18n``: probability that the page is
+    written in the Western European vocabulary (accented letters, ß, œ, € ...) mixed with the English one.  The truth lists the lines in READING
     order (header, title, first column top to bottom, second column, footer) in the upright frame plus ``angle``."""
     W, H = size
     rng = np.random.default_rng(seed)
@@ -337,6 +383,10 @@ def render_layout_page(seed: int, size: Tuple[int, int] = A4_300DPI, layout: Opt
     fboxes, ftexts, fpos = [], [], []
     fontset = FORMULA_FONTSETS[int(rng.integers(len(FORMULA_FONTSETS)))]
     block_id = [0]
+    vocab = None
+    if i18n > 0 and rng.random() < i18n:
+        vocab = list(_WORDS_I18N) * 2 + list(_WORDS)          # two thirds Western European words
+    random_text = lambda r, *a, **k: globals()["random_text"](r, *a, vocabulary=vocab, **k)    # noqa: E731
 
     def put(x: int, y: int, t: str, ff, max_x: int) -> Optional[int]:
         t = _font_safe(t, fname)

@@ -33,7 +33,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from ..models.crnn import CRNN
+from ..models.crnn import CRNN, DEFAULT_CHARSET
 from ..models.dbnet import DBNet
 from ..ops import ctc_loss as ctc_ops
 from ..ops import resample as rs
@@ -58,8 +58,10 @@ def augment_scan(pg: np.ndarray, rng: np.random.Generator) -> np.ndarray:
     return np.ascontiguousarray(out)
 
 
-def render_training_page(seed: int, fonts=None, plain_share: float = 0.2, max_skew: float = 5.0, formula_share: float = 0.4):
-    """One page of the training distribution (see the module docstring) and its truth."""
+def render_training_page(seed: int, fonts=None, plain_share: float = 0.2, max_skew: float = 5.0, formula_share: float = 0.4,
+                         i18n_share: float = 0.35):
+    """One page of the training distribution (see the module docstring) and its truth.  ``i18n_share`` of the layout
+    pages are written in the Western European vocabulary (accented letters, sharp s, ligatures, currency signs)."""
     rng = np.random.default_rng(seed)
     if rng.random() < plain_share:
         pg, truth = synth.render_page(seed, font_px=int(rng.integers(34, 50)), noise=float(rng.uniform(0.5, 4.0)))
@@ -68,7 +70,8 @@ def render_training_page(seed: int, fonts=None, plain_share: float = 0.2, max_sk
     blur = float(rng.uniform(0.3, 1.1)) if rng.random() < 0.4 else 0.0
     pg, truth = synth.render_layout_page(seed, fonts=fonts or synth.TRAIN_FONTS, skew=skew, blur=blur,
                                          noise=float(rng.uniform(0.5, 5.0)),
-                                         formulas=float(rng.uniform(0.3, 0.9)) if rng.random() < formula_share else 0.0)
+                                         formulas=float(rng.uniform(0.3, 0.9)) if rng.random() < formula_share else 0.0,
+                                         i18n=i18n_share)
     return augment_scan(pg, rng), truth
 
 
@@ -385,6 +388,11 @@ def evaluate(det, rec, device, seeds, verbose=False, formula_weights=None):
     out["plain"] = evaluate_pages(eng, [synth.render_page(sd) for sd in seeds[:4]], verbose)
     out["layout_train_fonts"] = evaluate_pages(eng, [render_training_page(sd, plain_share=0.0) for sd in seeds], verbose)
     out["held_out_fonts_skew3"] = evaluate_pages(eng, held_out_pages(seeds), verbose)
+    # Western European text in fonts never drawn in training (the Lato files cover the whole character set)
+    lato = [f for f in synth.HELD_OUT_FONTS if f.startswith("Lato")]
+    out["western_european_held_out_fonts"] = evaluate_pages(
+        eng, [synth.render_layout_page(sd, fonts=lato, i18n=1.0, layout=synth.LAYOUTS[k % len(synth.LAYOUTS)],
+                                       skew=2.0 * (1 if k % 2 == 0 else -1)) for k, sd in enumerate(seeds[:6])], verbose)
     out["formula_pages"] = evaluate_pages(eng, [synth.render_layout_page(sd, fonts=synth.TRAIN_FONTS, formulas=0.8,
                                                                          layout=synth.LAYOUTS[k % 3])
                                                 for k, sd in enumerate(seeds[:4])], verbose)
@@ -393,15 +401,16 @@ def evaluate(det, rec, device, seeds, verbose=False, formula_weights=None):
     return out
 
 
-def write_meta(out_dir: str, steps: int, ev, log) -> None:
+def write_meta(out_dir: str, steps: int, ev, log, charset: str = "") -> None:
     """``train_meta.json``: what the weights were trained on (fonts drawn, fonts never drawn) and how they score."""
-    json.dump({"steps": steps, "eval": ev, "log": log[-20:],
+    json.dump({"steps": steps, "eval": ev, "log": log[-20:], "charset": charset,
                "train_fonts": synth.available_fonts(synth.TRAIN_FONTS),
                "held_out_fonts": synth.available_fonts(synth.HELD_OUT_FONTS),
                "augmentation": {"skew_deg": 5.0, "blur_sigma": [0.3, 1.1], "noise_sigma": [0.5, 5.0],
                                 "contrast": [0.7, 1.15], "jpeg_quality": [35, 95], "font_px": [30, 50],
                                 "layouts": list(synth.LAYOUTS) + ["plain"],
-                                "display_formulas": "40 % of the layout pages carry formulas (synth.random_formula, mathtext)"}},
+                                "display_formulas": "40 % of the layout pages carry formulas (synth.random_formula, mathtext)",
+                                "western_european_pages": "35 % of the layout pages (synth._WORDS_I18N)"}},
               open(os.path.join(out_dir, "train_meta.json"), "w"), indent=1)
 
 
@@ -440,6 +449,12 @@ def main(argv=None) -> int:
         if os.path.exists(meta):
             start = int(json.load(open(meta)).get("steps", 0))
         print(f"resumed weights from {args.out} (step {start})", flush=True)
+    if rec.charset != DEFAULT_CHARSET:
+        # weights trained on fewer characters: grow the classifier, old classes keep their rows
+        n_old = len(rec.charset)
+        rec.set_charset(DEFAULT_CHARSET)
+        rec.to(device)
+        print(f"character set grown from {n_old} to {len(rec.charset)} characters", flush=True)
     det.train()
     rec.train()
     dopt, ropt = _Opt(det, args.det_lr), _Opt(rec, args.rec_lr)
@@ -488,7 +503,7 @@ def main(argv=None) -> int:
                 print(json.dumps({"step": it, "eval": ev}), flush=True)
                 save_bf16(det, dp)
                 save_bf16(rec, rp)
-                write_meta(args.out, it, ev, log)
+                write_meta(args.out, it, ev, log, rec.charset)
     finally:
         prod.stop()
         alive.set()
@@ -496,7 +511,7 @@ def main(argv=None) -> int:
                   formula_weights=fw)
     save_bf16(det, dp)
     save_bf16(rec, rp)
-    write_meta(args.out, it, ev, log)
+    write_meta(args.out, it, ev, log, rec.charset)
     print(json.dumps({"final_step": it, "eval": ev, "weights": args.out}), flush=True)
     return 0
 
