@@ -226,8 +226,9 @@ class OcrEngine:
         self._graphs: Dict[Tuple[int, int, int], "_RecGraph"] = {}
         cs = getattr(self.rec, "charset", "")
         self._lut = None
-        if cs and all(ord(c) < 256 for c in cs):
-            self._lut = np.frombuffer(("\0" + cs).encode("latin-1"), dtype=np.uint8)
+        if cs and all(ord(c) < 0x10000 and not 0xD800 <= ord(c) < 0xE000 for c in cs):
+            # class id -> code point (id 0 = CTC blank): strings are built by one gather + one UTF-32 decode per line
+            self._lut = np.frombuffer(("\0" + cs).encode("utf-32-le"), dtype=np.uint32)
         self.pages_done = 0
         self.lines_done = 0
 
@@ -807,7 +808,7 @@ class OcrEngine:
         a = ids.numpy()
         L = lens.numpy()
         ch = self._lut[np.clip(a, 0, len(self._lut) - 1)]
-        return [ch[i, : L[i]].tobytes().decode("latin-1") for i in range(a.shape[0])]
+        return [ch[i, : L[i]].tobytes().decode("utf-32-le") for i in range(a.shape[0])]
 
     # ------------------------------------------------------------------ public API
     def process_batches(self, batches: Iterable[Sequence[PageImage]]) -> Iterator[List[PageResult]]:

@@ -221,7 +221,7 @@ def torch_bf16():
 def write_config(path: Path, weights_dir: Path, recognizer: str = "crnn") -> dict:
     cfg = {"weights-dir": str(weights_dir), "recognizer": recognizer, "device-mode": "gfx950",
            "det": {"limit-side": 1344, "bin-thresh": 0.3, "box-thresh": 0.6, "unclip-ratio": 1.5},
-           "rec": {"height": 48, "charset": "ascii-printable"}}
+           "rec": {"height": 48, "charset": "from-weights (classifier rows select a prefix of models/crnn.py::DEFAULT_CHARSET)"}}
     path.write_text(json.dumps(cfg, indent=2))
     return cfg
 

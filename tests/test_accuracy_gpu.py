@@ -143,3 +143,33 @@ def test_display_formulas_are_found_read_and_kept_in_order(pipe):
     kinds = [it["type"] for it in doc.content_list]
     assert kinds.count("equation") == len(eqs) and all(it["text"].startswith("$$ ") for it in doc.content_list if it["type"] == "equation")
     assert "$$" in doc.text
+
+
+def test_western_european_text_in_held_out_fonts(pipe):
+    """German / French / Spanish / Italian / Portuguese / Scandinavian words (accented letters, sharp s, ligatures,
+    currency signs) in fonts the training never drew, pages turned by +-2 degrees, read through detector boxes; the
+    document's language is reported as not English."""
+    from distributed_llms_amd.models.crnn import LATIN_EXTRA
+    from distributed_llms_amd.train.page_trainer import evaluate_pages
+
+    assert all(c in pipe.engine.rec.charset for c in "äöüßéèçñåøœ€"), "the shipped recogniser reads ASCII only"
+    lato = [f for f in synth.HELD_OUT_FONTS if f.startswith("Lato")]
+    pages = [synth.render_layout_page(777_000 + k, fonts=lato, i18n=1.0, layout=synth.LAYOUTS[k % len(synth.LAYOUTS)],
+                                      skew=2.0 * (1 if k % 2 == 0 else -1)) for k in range(4)]
+    truth_text = "".join(t for _, tr in pages for t in tr.texts)
+    assert sum(c in LATIN_EXTRA for c in truth_text) > 300
+    ev = evaluate_pages(pipe.engine, pages)
+    print("Western European, held-out fonts:", ev)
+    assert ev["det_recall"] > 0.97, ev
+    assert ev["cer"] < 0.03, ev
+    # accented letters themselves (not just the ASCII around them): at most 6 % of them lost from the page text
+    pdf = synth.make_scanned_pdf([pages[0][0]], codec="jpeg")
+    doc = pipe.process_pdf(pdf, "i18n")
+    got = doc.text
+    want_acc = [c for c in "".join(pages[0][1].texts) if c in LATIN_EXTRA]
+    got_acc = [c for c in got if c in LATIN_EXTRA]
+    from collections import Counter
+
+    lost = sum((Counter(want_acc) - Counter(got_acc)).values())
+    assert lost <= 0.06 * len(want_acc), (lost, len(want_acc))
+    assert doc.language != "en" and doc.language != "und", (doc.language, doc.language_confidence)

@@ -146,3 +146,36 @@ def test_balanced_chunks_cut_a_document_into_equal_batches():
         sizes = [b - a for a, b in ch]
         assert ch[0][0] == 0 and ch[-1][1] == n and all(ch[i][1] == ch[i + 1][0] for i in range(len(ch) - 1))
         assert max(sizes) <= 7 and max(sizes) - min(sizes) <= 1 and len(ch) == -(-n // 7)
+
+
+def test_crnn_character_set_follows_the_checkpoint_and_grows_in_place(tmp_path):
+    """A checkpoint trained on printable ASCII (96 classifier rows) loads into a model built for the Western European
+    set, which then reads ASCII only; growing it back keeps the old classes' rows."""
+    from distributed_llms_amd.models.crnn import ASCII_CHARSET, DEFAULT_CHARSET, LATIN_EXTRA
+    from distributed_llms_amd.utils.weights import load_model_weights, save_model_weights
+
+    assert DEFAULT_CHARSET.startswith(ASCII_CHARSET) and len(set(DEFAULT_CHARSET)) == len(DEFAULT_CHARSET)
+    kw = dict(hidden=64, widths=(16, 32, 32, 32, 64, 64))
+    old = CRNN(charset=ASCII_CHARSET, **kw)
+    save_model_weights(old, str(tmp_path / "ascii.safetensors"))
+    net = CRNN(**kw)
+    assert net.num_classes == len(DEFAULT_CHARSET) + 1
+    load_model_weights(net, str(tmp_path / "ascii.safetensors"))
+    assert net.charset == ASCII_CHARSET and net.fc.out_features == 96
+    assert torch.equal(net.fc.weight, old.fc.weight)
+    net.set_charset(DEFAULT_CHARSET)
+    assert net.fc.out_features == len(DEFAULT_CHARSET) + 1 and torch.equal(net.fc.weight[:96], old.fc.weight)
+    assert net.encode_text("Straße 5 €") == [DEFAULT_CHARSET.index(c) + 1 for c in "Straße 5 €"]
+    x = torch.randn(2, 3, 48, 64)
+    assert net.eval()(x).shape[-1] == len(DEFAULT_CHARSET) + 1
+    # every extra character is something the page generator can write
+    from distributed_llms_amd.pdf import synth
+
+    vocab = set("".join(synth._WORDS_I18N))
+    assert all(c in vocab for c in LATIN_EXTRA)
+    pg, truth = synth.render_layout_page(7, size=(620, 877), fonts=["DejaVuSerif.ttf"], i18n=1.0)
+    text = "".join(truth.texts)
+    assert any(c in LATIN_EXTRA for c in text) and all(c in DEFAULT_CHARSET for c in text)
+    # the Computer Modern files carry TeX encodings: only ASCII is drawn with them, and the truth says so
+    assert synth._font_safe("Straße déjà 5 €", "cmr10.ttf") == "Strae dj 5"
+    assert synth._font_safe("Straße déjà 5 €", "DejaVuSans.ttf") == "Straße déjà 5 €"
