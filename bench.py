@@ -82,7 +82,7 @@ def parse_args():
     ap.add_argument("--weights", default=str(ROOT / "weights"), help="directory with dbnet/crnn .safetensors")
     ap.add_argument("--random-init", action="store_true", help="ignore trained weights")
     ap.add_argument("--recognizer", choices=["crnn", "trocr"], default="crnn",
-                    help="trocr: TrOCR-base-sized ViT + decoder (BASELINE config 4; random-init, generator line boxes)")
+                    help="trocr: TrOCR-base-sized ViT + decoder (random-init, generator line boxes)")
     ap.add_argument("--trocr-tokens", type=int, default=32)
     ap.add_argument("--via-pool", action="store_true",
                     help="drive runtime.workers.WorkerPool (the service's multi-GPU back end) from rank 0 instead of one "
@@ -347,7 +347,7 @@ def main():
                 "weights": "trained (weights/)" if trained else "random-init",
                 "cer_vs_truth": None if cer is None else round(cer, 5),
                 "baseline": "CPU proxy: same graphs, torch CPU eager, ProcessPoolExecutor(8) on 8 vCPU = 0.84 pages/s "
-                            "(BASELINE.md; the reference publishes no number)",
+                            "(bench/cpu_proxy.py; the reference publishes no number)",
             },
         }
         if args.stage_times:

@@ -6,7 +6,7 @@ Three ways to run:
   ranks, ONE JSON line from rank 0 (bus bandwidth of the faster of the direct kernel and RCCL; both are listed).
   ``--cpu`` times gloo on host tensors (contract check on machines without GPUs);
 * ``--sweep`` under torchrun on a multi-GPU node (one rank per GPU, RCCL group): also times ``dist.all_reduce`` (RCCL)
-  on the same buffers, which is the comparison SURVEY 5.8 asks for;
+  on the same buffers;
 * plain ``python bench/allreduce_bench.py --ranks 4`` on a one-GPU box: the ranks are processes that share
   cuda:0 (gloo carries the IPC handles).  That measures the barrier / launch latency floor and an HBM-bound
   bandwidth, not xGMI; RCCL cannot be compared there (it refuses two ranks on one device).

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""CPU proxy for the reference's execution model (BASELINE.md).
+"""CPU proxy for the reference's execution model.
 
 The reference runs a third-party CPU OCR stack (magic-pdf) inside ``ProcessPoolExecutor(os.cpu_count())``
 (services/ocr_service/ocr_service.py:42, 274-278).  That stack cannot be installed here, so this script runs the

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Service-level benchmark through real HTTP (BASELINE configs 1 and 2 as a client sees them).
+"""Service-level benchmark through real HTTP.
 
 Starts the ASGI app under uvicorn as a child process (in-memory stores unless REDIS_* / MONGO_* are set), then
   1. config 1: N single-page born-digital PDFs through /extract -> /check-status -> /result: p50 / p95 latency;

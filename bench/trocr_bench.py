@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""BASELINE config 4: ViT-encoder + Transformer-decoder recognizer (TrOCR-base-sized), bf16, one MI355X.
+"""ViT-encoder + Transformer-decoder recognizer (TrOCR-base-sized), bf16, one MI355X.
 
 Reports line crops/sec for encode + greedy decode of ``--tokens`` tokens per crop (hipGraph-replayed steps),
 the encoder-only rate, and the equivalent pages/sec at ``--lines-per-page`` lines."""

@@ -1,4 +1,4 @@
-// Fused multi-tensor AdamW over a flat parameter bucket (SURVEY N16).
+// Fused multi-tensor AdamW over a flat parameter bucket.
 //
 // Parameters, gradients and both moments of a whole DP bucket are contiguous
 // (parallel/ddp.py FlatBuckets), so one launch updates tens of MB with 16-byte

@@ -3,9 +3,9 @@
 // One kernel family serves every GEMM-shaped op of the OCR stack:
 //   * DBNet backbone / FPN / head convolutions (NHWC bf16, any kh x kw, stride, pad)
 //   * 1x1 convolutions and plain GEMMs  y[M,N] = x[M,K] . w[N,K]^T  (H=1, W=M)
-//   * transposed conv 2x2 stride 2 (GEMM + pixel-shuffle store)          
+//   * transposed conv 2x2 stride 2 (GEMM + pixel-shuffle store)
 //   * FPN "nearest-upsample + add" fused on the residual read, and
-//     "upsample xf + concat" fused on the store                          
+//     "upsample xf + concat" fused on the store
 //   * bias + ReLU / hardswish / GELU / sigmoid epilogues; the DB head's
 //     sigmoid + threshold epilogue emits probability map and bitmask.
 //

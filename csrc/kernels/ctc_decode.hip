@@ -1,5 +1,5 @@
-// CTC greedy decode (SURVEY N9) and generic row argmax (used by the
-// Transformer decoder's LM head, SURVEY N13).
+// CTC greedy decode and generic row argmax (used by the
+// Transformer decoder's LM head).
 //
 //   row_argmax : one wave64 per (sample, time) row of logits [R, V]; online
 //                max / argmax / sum-exp with 16-byte vector loads, so the max

@@ -1,4 +1,4 @@
-// CTC loss forward + gradient w.r.t. the logits (BASELINE config 5).
+// CTC loss forward + gradient w.r.t. the logits.
 //
 //   1. ctc_lse_kernel     log-sum-exp of every (sample, time) row of the logits:
 //                         one wave64 per row, fully parallel over N*T rows.

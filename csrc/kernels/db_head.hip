@@ -1,5 +1,5 @@
 // DB head tail, fused: deconv 2x2/s2 (64 -> 64, folded BN, ReLU) + deconv 2x2/s2 (64 -> 1) + sigmoid + threshold
-// in one kernel (SURVEY N5).  Unfused, the first deconv writes a [B, H/2, W/2, 64] bf16 map (660 MB for a 25-page
+// in one kernel.  Unfused, the first deconv writes a [B, H/2, W/2, 64] bf16 map (660 MB for a 25-page
 // batch) that the second one reads straight back; both launches are pure memory traffic (44 - 57 TFLOP/s in
 // bench/conv_layer_breakdown.py).  Fused, only the probability map and the bit mask leave the chip.
 //

@@ -1,4 +1,4 @@
-// DB (differentiable binarisation) post-processing on the GPU (SURVEY N6).
+// DB (differentiable binarisation) post-processing on the GPU.
 //
 // Replaces the OpenCV findContours + pyclipper + shapely chain of the
 // reference's dependency stack with four small kernels that never move the

@@ -1,4 +1,4 @@
-// Direct (all-links) all-reduce over HIP IPC peer buffers for one xGMI node (SURVEY 5.8, N15).
+// Direct (all-links) all-reduce over HIP IPC peer buffers for one xGMI node.
 //
 // MI355X's intra-node fabric is a fully connected mesh: 7 xGMI links per GPU.  A ring collective
 // drives one outbound link per GPU; this kernel instead lets every rank read a distinct 1/N shard
@@ -20,7 +20,7 @@
 // acquire, vmcnt(0), workgroup barrier, plain loads.  Spins are bounded: a rank whose peer never
 // arrives sets a status word and leaves, so the grid always drains.
 //
-// The reference has no collective of any kind (SURVEY 2D); this is new for DP recognizer training.
+// The reference has no collective of any kind; this is new for DP recognizer training.
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>

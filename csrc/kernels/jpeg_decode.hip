@@ -1,4 +1,4 @@
-// Baseline JPEG decode on the GPU (SURVEY N2 "decode page image", hard part 7.4-7).
+// Baseline JPEG decode on the GPU.
 //
 // A 300-DPI A4 scan is 8.7 Mpixel; libjpeg-turbo needs ~55 ms per page per CPU
 // core, which caps a 16-core host at ~280 pages/s and would starve the GPU

@@ -1,4 +1,4 @@
-// Bidirectional LSTM recurrence for the CRNN recognizer (hard part 7.4-4).
+// Bidirectional LSTM recurrence for the CRNN recognizer.
 //
 // The input projection x.W_ih^T + b for ALL time steps is one large MFMA GEMM
 // (conv_igemm, 1x1 path).  This kernel runs only the sequential part and is

@@ -1,4 +1,4 @@
-// Training kernels for the CRNN's bidirectional LSTM (SURVEY N8 + BASELINE config 5).
+// Training kernels for the CRNN's bidirectional LSTM.
 //
 // PyTorch's LSTM under bf16 autocast on ROCm runs one GEMM + one cell kernel per time step, per
 // direction, per layer, forward and backward: ~10 000 launches per training step (profiles/15), which

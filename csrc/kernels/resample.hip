@@ -1,4 +1,4 @@
-// Page raster -> tensor (SURVEY N2) and line crop + resize (SURVEY N7).
+// Page raster -> tensor and line crop + resize.
 //
 // One fused kernel: for every output item (a whole page for detection, a text
 // line box for recognition) read a rectangular region of a u8 source image

@@ -1,4 +1,4 @@
-// Transformer building blocks for the TrOCR-sized recognizer (SURVEY N12, N13):
+// Transformer building blocks for the TrOCR-sized recognizer:
 //   layernorm_kernel        one wave64 per token row, fp32 statistics, bf16 in/out, 16-byte accesses
 //   attention_fwd_kernel    flash-style attention on MFMA for full sequences (ViT encoder, 577 tokens):
 //                           K/V streamed through LDS in 64-key blocks with online softmax

@@ -1,7 +1,7 @@
 // C ABI of the native PDF reader (loaded from Python with ctypes; every call releases the GIL,
 // so page analysis and image decoding run in parallel on the host thread pool).
 //
-// Replaces PyMuPDF + pdfminer in the reference's stack (SURVEY 2C, N1):
+// Replaces PyMuPDF + pdfminer in the reference's stack:
 //   services/ocr_service/ocr_service.py:210  PymuDocDataset(pdf_bytes)
 //   services/ocr_service/ocr_service.py:213  ds.classify()
 #include <algorithm>

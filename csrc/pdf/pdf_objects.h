@@ -1,4 +1,4 @@
-// Minimal PDF object model + lexer/parser for the native reader (SURVEY N1, 2C).
+// Minimal PDF object model + lexer/parser for the native reader.
 // Written from the PDF 1.7 specification (ISO 32000-1); replaces PyMuPDF in the
 // reference's stack (services/ocr_service/requirements.txt:214).
 #pragma once

@@ -1,4 +1,4 @@
-// Page-level dynamic batcher (SURVEY N10) - native host component of the GPU worker.
+// Page-level dynamic batcher - native host component of the GPU worker.
 //
 // Pages (detector inputs) and crops arrive one by one from the decode pool, possibly from many
 // documents at once.  A batch must be shape-uniform (one detector bucket Hd x Wd), fit the HBM

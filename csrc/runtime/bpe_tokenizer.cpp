@@ -1,6 +1,6 @@
 // Byte-level BPE vocabulary (GPT-2 / RoBERTa family, the vocabulary TrOCR-sized decoders use) in C++.
 //
-// the reference reaches the Rust `tokenizers` wheel through its recognizers
+// The reference reaches the Rust `tokenizers` wheel through its recognizers
 // (requirements.txt:293); this is the in-repo native replacement.  Two vocabularies:
 //   * the built-in raw byte vocabulary: ids 0..3 = <s>, <pad>, </s>, <unk>; ids 4..259 = bytes 0..255
 //     (what models/trocr.py uses when no vocab file is given);

@@ -1,4 +1,4 @@
-// Host-code sanitizer harness (SURVEY 5.2): the native PDF reader, JPEG scanner, dynamic batcher and BPE
+// Host-code sanitizer harness: the native PDF reader, JPEG scanner, dynamic batcher and BPE
 // vocabulary compiled with -fsanitize=address,undefined and driven with (a) well-formed documents given on the
 // command line and (b) thousands of mutated / truncated copies of them.  Any heap overflow, use-after-free,
 // signed overflow or misaligned access aborts the run; malformed input must only ever produce error codes.

@@ -1,6 +1,6 @@
 # Machine image of the status-store node: Redis with AOF persistence, started at boot.
 # (Role of terraform/ami_redis.pkr.hcl in the reference, with persistence switched on - the reference's
-# Redis AMI ran without it, SURVEY 5.4.)
+# Redis AMI ran without it)
 packer {
   required_plugins {
     amazon = { source = "github.com/hashicorp/amazon", version = ">= 1.2.0" }

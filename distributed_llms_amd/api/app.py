@@ -1,4 +1,4 @@
-"""HTTP API (call stacks 3.1, 3.3, 3.4).
+"""HTTP API.
 
 Same public contract as the reference service
 (services/ocr_service/ocr_service.py:127-195, 412-606; API.md):
@@ -7,11 +7,11 @@ Same public contract as the reference service
     GET  /check-status/{id}      -> {"status": processing|completed|error} | 404 {'status': 'unknown', 'error': ...}
     GET  /result/{id}            -> {"document_id", "text", "status": "completed"} | in-progress status | 404 | 500
     GET  /health                 -> healthy 200 | degraded 200 | unhealthy 503, version "1.0.0"
-    GET  /metrics                -> Prometheus text (new, SURVEY 5.5)
+    GET  /metrics                -> Prometheus text (new)
 
 Built as a FastAPI app (CORS wide open like the reference, lifespan-managed stores).  The
 multipart body is parsed by ``api.multipart`` because python-multipart - which FastAPI's
-``File``/``Form`` need - is not a dependency here.  Deliberate fixes, all listed in SURVEY 2B/5:
+``File``/``Form`` need - is not a dependency here.  Deliberate fixes:
 an empty ``document_id`` really answers 400 (the reference *returns* the exception object);
 the duplicate check and the ``queued`` write are one atomic claim; no Redis call blocks the
 event loop; there is no default Mongo credential.

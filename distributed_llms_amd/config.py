@@ -1,4 +1,4 @@
-"""Typed settings object (SURVEY 5.6, R14).
+"""Typed settings object.
 
 Same environment variable names and defaults as the reference
 (services/ocr_service/ocr_service.py:32-34, 56-58, 610 and the never-imported

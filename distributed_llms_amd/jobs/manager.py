@@ -1,17 +1,17 @@
-"""Document job state machine (SURVEY R7, 2B-1, 2B-2, 2B-9, 5.3).
+"""Document job state machine.
 
 Lifecycle in the status store:  queued -> processing -> completed | failed
 (services/ocr_service/ocr_service.py:453, 265, 292/376, 305/328).  The write order on
-success is the reference's (2B-2): result-store upsert -> status {completed, result_preview}
+success is the reference's: result-store upsert -> status {completed, result_preview}
 -> status {completed, document_hash, result (full text)}; the result row therefore exists
 before any reader can see ``completed``.  Failures write ``failed`` + error and drop
-``output/error_{id}.json`` for the log agent (R10).
+``output/error_{id}.json`` for the log agent.
 
-What is new relative to the reference (all called out in SURVEY 5.2/5.3):
+What is new relative to the reference:
 * the ``queued`` claim is atomic (``SET NX``), so two replicas cannot both start one id;
 * status records carry ``owner`` (node id) so a restarted node can fail its orphans;
 * a per-document deadline turns a stuck extraction into ``failed`` instead of hanging forever;
-* every status write and store call runs in the I/O thread pool, never on the event loop (2B-10);
+* every status write and store call runs in the I/O thread pool, never on the event loop;
 * per-stage latencies are recorded for /metrics (5.1, 5.5).
 """
 from __future__ import annotations
@@ -141,7 +141,7 @@ class JobManager:
             await asyncio.wait(list(self.tasks), timeout=timeout)
 
     def sweep_orphans(self) -> int:
-        """On startup: documents this node left in queued/processing before a restart become failed (2B-9)."""
+        """On startup: documents this node left in queued/processing before a restart become failed."""
         return self.status.sweep_orphans(owner=self.node_id or None, reason="service restarted")
 
     def shutdown(self) -> None:

@@ -1,4 +1,4 @@
-"""CRNN line recognizer (SURVEY N8): conv stack -> 2 x BiLSTM(256) -> Linear -> CTC.
+"""CRNN line recognizer: conv stack -> 2 x BiLSTM(256) -> Linear -> CTC.
 
 Input crops are ``[N, 48, W, 8]`` NHWC bf16 (3 real channels), W a bucket width
 (multiple of 32).  The conv stack reduces height 48 -> 1 and width by 4, so
@@ -8,7 +8,7 @@ ceil(valid_w / 4) which the persistent LSTM kernel and the CTC decoder honour.
 Inference path: 6 MFMA implicit-GEMM convs, per LSTM layer one projection GEMM
 + one persistent recurrent kernel, one FC GEMM, CTC greedy decode - 13 kernel
 launches per batch, captured in one hipGraph per (batch, width) bucket by the
-runtime (SURVEY N17).
+runtime.
 
 Training path (``forward``): the same parameters through PyTorch autograd
 (nn.LSTM / MIOpen), used by train/ with the HIP CTC loss and fused AdamW.

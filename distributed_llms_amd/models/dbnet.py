@@ -1,4 +1,4 @@
-"""DBNet-style text detector (SURVEY N3-N5).
+"""DBNet-style text detector.
 
 ResNet-18-shaped backbone + FPN neck + DB probability head, re-designed for
 the MI355X inference path:

@@ -94,7 +94,7 @@ class ConvBNAct(nn.Module):
 
 
 class Deconv2x2(nn.Module):
-    """ConvTranspose2d(k=2, s=2) (+BN) (+act) = GEMM + pixel-shuffle store (SURVEY N5)."""
+    """ConvTranspose2d(k=2, s=2) (+BN) (+act) = GEMM + pixel-shuffle store."""
 
     def __init__(self, cin: int, cout: int, act: str = "relu", bn: bool = True):
         super().__init__()

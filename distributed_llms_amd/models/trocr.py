@@ -1,4 +1,4 @@
-"""ViT-encoder + Transformer-decoder line recognizer, TrOCR-base-sized (BASELINE config 4).
+"""ViT-encoder + Transformer-decoder line recognizer, TrOCR-base-sized.
 
 Sizes (defaults): 384 x 384 crop -> 24 x 24 patches of 16 x 16 + CLS = 577 tokens, encoder 12 x
 (d = 768, 12 heads, MLP 3072); decoder 12 x (d = 1024, 16 heads, FFN 4096, cross-attention over the
@@ -15,7 +15,7 @@ MI355X inference path (``encode`` / ``generate``):
 * one greedy decode step (embed -> 12 layers -> LM-head GEMM -> argmax -> step counter) has fully static
   launch parameters: the step index lives in device memory and the decode-attention kernel appends to the
   KV cache itself, so the whole step (~140 launches) is captured ONCE per batch bucket in a hipGraph and
-  replayed per generated token (N17).  Decode is GEMV-shaped at small batch, so crops are batched (>= 256).
+  replayed per generated token.  Decode is GEMV-shaped at small batch, so crops are batched (>= 256).
 
 ``forward_reference`` is the plain PyTorch fp32 implementation over the same parameters (test oracle).
 In the reference service this role is played by magic-pdf's UniMERNet / OCR recognizers on CPU

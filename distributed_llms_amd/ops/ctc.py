@@ -1,4 +1,4 @@
-"""CTC greedy decode + row argmax (SURVEY N9, N13 LM-head argmax).
+"""CTC greedy decode + row argmax.
 
 GPU: ``dlamd_row_argmax`` + ``dlamd_ctc_collapse`` (csrc/kernels/ctc_decode.hip).
 CPU / oracle: pure PyTorch.

@@ -1,4 +1,4 @@
-"""CTC loss with a fused forward + gradient HIP kernel (SURVEY N14).
+"""CTC loss with a fused forward + gradient HIP kernel.
 
 ``ctc_loss(logits, targets, input_lens, target_lens)`` takes *raw logits*
 ``[N, T, V]`` (log-softmax is fused into the kernel) and returns per-sample

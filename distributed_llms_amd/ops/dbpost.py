@@ -1,4 +1,4 @@
-"""DB post-processing: probability map -> text boxes (SURVEY N6).
+"""DB post-processing: probability map -> text boxes.
 
 GPU path: ``dlamd_db_postprocess`` (csrc/kernels/db_postprocess.hip) -
 union-find connected components, per-component statistics and closed-form
@@ -10,7 +10,7 @@ CPU path / oracle: ``db_postprocess_reference`` (scipy.ndimage.label with
 The reference stack does this with OpenCV findContours + pyclipper + shapely
 (services/ocr_service/requirements.txt:160,200,271) inside magic-pdf.
 Thresholds default to the published DBNet values (binarise 0.3, box score
-0.6, unclip ratio 1.5) - see the provenance warning in SURVEY.md 2E.
+0.6, unclip ratio 1.5); the values magic-pdf actually ships are not visible in the reference's files.
 """
 from __future__ import annotations
 

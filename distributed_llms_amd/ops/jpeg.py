@@ -1,4 +1,4 @@
-"""JPEG page-image decode (hard part 7.4-7).
+"""JPEG page-image decode.
 
 GPU path (csrc/kernels/jpeg_decode.hip): a whole batch of baseline JPEGs per call.  Streams with restart markers
 take one lane per restart segment (``dlamd_jpeg_decode``, two launches); streams without - what most scanners

@@ -1,4 +1,4 @@
-"""(Bi)LSTM layer for the CRNN recognizer (SURVEY N8).
+"""(Bi)LSTM layer for the CRNN recognizer.
 
 Split exactly the way the hardware wants it:
   * input projection for all time steps = one big MFMA GEMM (``linear_bf16``)

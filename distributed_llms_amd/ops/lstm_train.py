@@ -7,7 +7,7 @@ time step (the eager path needs ~10 000 launches per CRNN training step; ``profi
 
 Semantics are those of ``nn.LSTM(bidirectional=True, batch_first=True)`` fed a packed sequence and padded
 back: steps at ``t >= len`` output zeros and receive no gradient; the reverse direction starts at ``len-1``.
-The reference has no training code (SURVEY 2D); nothing to cite there.
+The reference has no training code; nothing to cite there.
 """
 from __future__ import annotations
 

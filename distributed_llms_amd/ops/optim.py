@@ -1,4 +1,4 @@
-"""Fused AdamW over flat parameter buckets (SURVEY N16).
+"""Fused AdamW over flat parameter buckets.
 
 One ``dlamd_adamw`` launch updates a whole flat bucket (parallel/ddp.py) - or, in
 ``rs_ag`` data-parallel mode, just this rank's 1/N shard of it - instead of one

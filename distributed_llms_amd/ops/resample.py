@@ -1,4 +1,4 @@
-"""Page raster -> tensor and line-crop ops (SURVEY N2 / N7).
+"""Page raster -> tensor and line-crop ops.
 
 ``resample_regions`` turns a list of rectangular regions of u8 source images
 (whole pages for detection, text-line boxes for recognition) into one padded

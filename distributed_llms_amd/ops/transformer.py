@@ -1,4 +1,4 @@
-"""Transformer ops for the TrOCR-sized recognizer (SURVEY N12, N13): LayerNorm, flash attention (MFMA),
+"""Transformer ops for the TrOCR-sized recognizer: LayerNorm, flash attention (MFMA),
 single-query decode attention over a KV cache, embedding gather.  GPU: csrc/kernels/transformer.hip;
 CPU tensors: plain PyTorch fp32 (also the oracle in tests)."""
 from __future__ import annotations

@@ -1,7 +1,7 @@
-"""Process-group bootstrap: one process per GPU, ``torch.distributed`` over RCCL/xGMI (SURVEY 5.8).
+"""Process-group bootstrap: one process per GPU, ``torch.distributed`` over RCCL/xGMI.
 
-The reference has no collective backend at all (SURVEY 2D: replicas only talk to
-Redis/Mongo); this is new for recognizer training (BASELINE config 5) and for
+The reference has no collective backend at all (replicas only talk to
+Redis/Mongo); this is new for recognizer training and for
 the bench's cross-rank timing.  ``backend="nccl"`` IS RCCL on ROCm; CPU-only
 hosts (CI, tests) use gloo with the same code path.
 """

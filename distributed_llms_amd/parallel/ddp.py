@@ -1,4 +1,4 @@
-"""Bucketed, backward-overlapped gradient all-reduce for data-parallel training (SURVEY N15, 5.8).
+"""Bucketed, backward-overlapped gradient all-reduce for data-parallel training.
 
 Design for MI355X: xGMI is a point-to-point mesh (7 links x ~153 GB/s per GPU), so a
 collective is bound by per-link bandwidth and by launch latency, not by a switch.

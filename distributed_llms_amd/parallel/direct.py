@@ -1,7 +1,7 @@
-"""Direct (all-links) all-reduce over HIP IPC peer buffers for one xGMI node (SURVEY 5.8, N15).
+"""Direct (all-links) all-reduce over HIP IPC peer buffers for one xGMI node.
 
 RCCL stays the default collective backend; this is the hand-written two-phase
-reduce-scatter + all-gather kernel SURVEY 5.8 asks for, for the bucket sizes where a ring is
+reduce-scatter + all-gather kernel, for the bucket sizes where a ring is
 bound by one xGMI link (7 links x ~153 GB/s per GPU, point to point): every rank reads a
 distinct 1/N shard from each peer at once, so all links carry traffic, and small buckets take a
 one-shot path (every rank sums all N buffers itself; one barrier, latency bound).  The kernel is
@@ -9,7 +9,7 @@ one-shot path (every rank sums all N buffers itself; one barrier, latency bound)
 buffers, exports them with ``hipIpcGetMemHandle``, the 128-byte handle pairs travel through the
 process group (``all_gather_object``), and every rank maps its peers' buffers.
 
-The reference has no collective backend at all (SURVEY 2D); nothing to cite there.
+The reference has no collective backend at all; nothing to cite there.
 
 Collective contract: every rank calls ``all_reduce_`` with the same shape / dtype / algo in the same
 order.  Results are bitwise identical on every rank (fixed summation order, fp32 accumulation).

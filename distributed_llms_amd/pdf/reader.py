@@ -1,6 +1,6 @@
 """ctypes binding of the native C++ PDF reader (``csrc/pdf`` -> ``libdlamd_pdf.so``).
 
-Role in the pipeline (SURVEY N1): what ``PymuDocDataset(pdf_bytes)`` +
+Role in the pipeline: what ``PymuDocDataset(pdf_bytes)`` +
 ``ds.classify()`` do in the reference (services/ocr_service/ocr_service.py:210-213):
 open a PDF from bytes, extract born-digital text, find the page images of
 scans, and decide TXT vs OCR.  Every native call releases the GIL, so page

@@ -1,16 +1,16 @@
 """Synthetic documents: rendered "scanned" pages, text lines for recognizer training, and PDF files.
 
 There is no dataset and no network in the build environment, and the reference
-ships no fixtures (SURVEY.md 4), so every workload is generated here:
+ships no fixtures, so every workload is generated here:
 
 * ``render_page``      - one A4 page at 300 DPI (2480 x 3508, 8-bit gray) with
   paragraphs of text, plus the ground-truth line boxes and strings;
-* ``render_line``      - one text-line crop for CTC training (BASELINE config 5);
+* ``render_line``      - one text-line crop for CTC training;
 * ``make_scanned_pdf`` - a PDF whose pages are one full-page image XObject each
   (DCTDecode with restart markers, or FlateDecode) - the shape a scanner emits
-  and the workload of BASELINE configs 2 and 3;
+  and the workload of the scanned-document benchmarks;
 * ``make_text_pdf``    - a born-digital PDF with Type-1 Helvetica text
-  (BASELINE config 1; exercises the C++ reader's text operators).
+  (exercises the C++ reader's text operators).
 
 PIL (with FreeType and libjpeg-turbo) is the only dependency.
 """

@@ -1,4 +1,4 @@
-"""ctypes binding of the native dynamic batcher (``csrc/runtime/batcher.cpp``, SURVEY N10).
+"""ctypes binding of the native dynamic batcher (``csrc/runtime/batcher.cpp``).
 
 ``DynamicBatcher`` groups work items (pages for detection, crops for recognition) by a shape
 key under a device-memory budget and a max-wait deadline.  The budget defaults to what a

@@ -1,4 +1,4 @@
-"""Document-level extraction: PDF bytes -> combined text (call stack 3.2).
+"""Document-level extraction: PDF bytes -> combined text.
 
 This is the MI355X-native ``process_pdf_sync`` (services/ocr_service/ocr_service.py:201-255):
 
@@ -55,7 +55,7 @@ _MD_MARKS = re.compile(r"\*\*|\*|__|\||---|___")
 
 
 def combine_text(content_list: Sequence, markdown: str = "") -> str:
-    """The reference's combined-text rule (ocr_service.py:229-248, SURVEY 2B-7)."""
+    """The reference's combined-text rule (ocr_service.py:229-248)."""
     out = ""
     for item in content_list:
         if isinstance(item, dict) and "text" in item:

@@ -1,12 +1,12 @@
-"""Single-GPU OCR engine: page images -> text lines (SURVEY 3.2 hot loop, N2-N9, N17).
+"""Single-GPU OCR engine: page images -> text lines.
 
 This is the MI355X replacement for what the reference delegates to magic-pdf's
 CPU models (services/ocr_service/ocr_service.py:215-216: ``doc_analyze`` +
 ``pipe_ocr_mode``).  One engine instance owns one GPU:
 
-    u8 pages --H2D--> resample (N2) --> DBNet (N3-N5) --> DB post-process (N6)
+    u8 pages --H2D--> resample --> DBNet --> DB post-process
         --boxes D2H--> crop table (host, reading order + width buckets)
-        --> crop/resize (N7) --> CRNN (N8) --> CTC greedy decode (N9) --ids D2H--> strings
+        --> crop/resize --> CRNN --> CTC greedy decode --ids D2H--> strings
 
 Design points
 * Two batches are always in flight on two HIP streams (software pipeline run
@@ -17,7 +17,7 @@ Design points
 * Recognition batches are grouped by crop width bucket; small buckets replay a
   captured hipGraph (``GraphCache``), large ones launch eagerly (13 launches
   against tens of ms of MFMA work).
-* ``layout_prior``: with random-init weights (the BASELINE workload) the
+* ``layout_prior``: with random-init weights the
   detector emits no meaningful boxes, so a caller may attach the page's known
   line boxes; they are used ONLY when the detector itself found nothing usable
   for that page.  Detector and post-process always run in full.
@@ -140,7 +140,7 @@ class EngineConfig:
 
 
 class StageTimer:
-    """Per-stage wall-clock accumulators (SURVEY 5.1)."""
+    """Per-stage wall-clock accumulators."""
 
     def __init__(self) -> None:
         self.t: Dict[str, float] = {}
@@ -212,7 +212,7 @@ class OcrEngine:
             torch.random.set_rng_state(g)
         self.det = det.to(self.device).prepare()
         self.rec = rec.to(self.device).prepare()
-        # OCR_RECOGNIZER=trocr: ViT encoder + transformer decoder instead of the CRNN (SURVEY N12/N13, 5.6)
+        # OCR_RECOGNIZER=trocr: ViT encoder + transformer decoder instead of the CRNN
         self.rec_kind = "crnn" if isinstance(rec, CRNN) else "trocr"
         self._trocr_event = None      # the decoder's static graph state is shared by both pipeline slots
         self._formula_event = None
@@ -451,7 +451,7 @@ class OcrEngine:
 
     # ------------------------------------------------------------------ recognition stage
     def _plan_crops(self, db: _DetBatch, det_boxes):
-        """Host side of N7: choose boxes per page, compute crop geometry, group by width bucket.  ``boxes`` carries
+        """Host side of the line crops: choose boxes per page, compute crop geometry, group by width bucket.  ``boxes`` carries
         the line angle in column 4."""
         cfg = self.cfg
         per_page = []
@@ -903,7 +903,7 @@ class OcrEngine:
 
 
 class _RecGraph:
-    """hipGraph-captured recognition step for one (crop-count bucket, width bucket) - SURVEY N17.
+    """hipGraph-captured recognition step for one (crop-count bucket, width bucket).
 
     Static inputs: the crop table and valid lengths (one device blob, refreshed with a
     single H2D copy per replay).  Static outputs: ids / lengths / confidences."""

@@ -1,4 +1,4 @@
-"""Extraction back ends behind the job orchestrator (the L2 -> L3 boundary of SURVEY 1).
+"""Extraction back ends behind the job orchestrator (the boundary between job orchestration and the engine).
 
 ``extract(pdf_bytes, document_id)`` is the equivalent of the reference's
 ``process_pdf_sync`` (services/ocr_service/ocr_service.py:201-255) and returns the same

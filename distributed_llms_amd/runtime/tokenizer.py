@@ -1,4 +1,4 @@
-"""ctypes binding of the native byte-level BPE vocabulary (``csrc/runtime/bpe_tokenizer.cpp``, SURVEY 2C).
+"""ctypes binding of the native byte-level BPE vocabulary (``csrc/runtime/bpe_tokenizer.cpp``).
 
 The reference reaches the Rust ``tokenizers`` wheel through magic-pdf's recognizers
 (services/ocr_service/requirements.txt:293).  Here the TrOCR-sized decoder's ids are turned into text

@@ -1,4 +1,4 @@
-"""GPU worker pool: data-parallel page sharding across the GPUs of one node (SURVEY N11, 2D, 5.3).
+"""GPU worker pool: data-parallel page sharding across the GPUs of one node.
 
 The reference scales by running N stateless copies of the whole service behind a load
 balancer, each extracting documents in a ``ProcessPoolExecutor(os.cpu_count())``
@@ -6,11 +6,11 @@ balancer, each extracting documents in a ``ProcessPoolExecutor(os.cpu_count())``
 front end owns N worker *processes*, one per MI355X:
 
 * a document's PDF bytes are placed in POSIX shared memory ONCE; workers map it and parse it
-  with the native reader (no per-page pickling across the process boundary, cf. 2B-11);
+  with the native reader (no per-page pickling across the process boundary);
 * its pages are split into contiguous shards handed to the least-loaded workers; each worker
-  batches the pages it holds - across documents - with the native dynamic batcher (N10) and runs
+  batches the pages it holds - across documents - with the native dynamic batcher and runs
   them through its ``OcrEngine``; per-page results come back on a queue and are gathered in page
-  order by the front end (inference needs no collectives: GPUs stay independent, SURVEY 5.8);
+  order by the front end (inference needs no collectives: GPUs stay independent);
 * every worker heartbeats; the supervisor re-queues the shards of a dead worker onto the
   survivors and respawns it (the reference's pool would raise BrokenProcessPool forever, 5.3);
 * ``FAULT_INJECT`` (settings.fault_inject) hooks make those paths testable:

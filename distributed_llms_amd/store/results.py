@@ -1,6 +1,6 @@
-"""Result store, error sink and image writer (SURVEY R9, R10, R13, 2B-8).
+"""Result store, error sink and image writer.
 
-The Mongo document is this repository's "checkpoint format" (BASELINE.json):
+The Mongo document is this repository's "checkpoint format":
 
     document_id: str, combined_text: str, status: 'completed',
     processed_at: datetime, word_count: int (= len(text.split())),
@@ -96,7 +96,7 @@ class FileResultStore(ResultStore):
     """Result rows as one JSON file each under ``<dir>/<sha1(document_id)>.json`` (atomic rename).
 
     For a single node with several front-end processes and no MongoDB (``OCR_STORE=redis+file``): every
-    process sees every row through the shared directory.  Same row schema as Mongo (2B-8); ``processed_at`` is
+    process sees every row through the shared directory.  Same row schema as Mongo; ``processed_at`` is
     stored as an ISO string and handed back as ``datetime``."""
 
     def __init__(self, directory: str):

@@ -1,4 +1,4 @@
-"""Document status store (SURVEY R8, 2B-1..2B-4).
+"""Document status store.
 
 Key layout and TTL are the reference's (services/ocr_service/ocr_service.py:63-108):
 
@@ -9,7 +9,7 @@ Every write re-arms the 24 h TTL.  All errors are swallowed and reported as
 ``False`` / ``None`` exactly like the reference helpers, so a Redis outage
 degrades the API instead of crashing it.
 
-Fix over the reference (SURVEY 5.2): the ``queued`` claim can be made atomic with
+Fix over the reference: the ``queued`` claim can be made atomic with
 ``claim()`` (``SET ... NX EX``) so two replicas cannot both start the same id.
 """
 from __future__ import annotations
@@ -135,7 +135,7 @@ class StatusStore:
     def sweep_orphans(self, owner: Optional[str] = None, reason: str = "worker restarted") -> int:
         """Mark ``queued``/``processing`` documents (optionally only those owned by ``owner``) as failed.
 
-        The reference strands such keys for 24 h after a restart (SURVEY 2B-9, 5.3)."""
+        The reference strands such keys for 24 h after a restart."""
         n = 0
         try:
             for key in list(self._keys("doc:*")):

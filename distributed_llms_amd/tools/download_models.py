@@ -1,4 +1,4 @@
-"""Fetch pretrained OCR checkpoints and write the engine's model config (SURVEY R15).
+"""Fetch pretrained OCR checkpoints and write the engine's model config.
 
 Counterpart of the reference's ``download_models_hf.py`` (services/ocr_service/download_models_hf.py:9-74), which
 pulls ``opendatalab/PDF-Extract-Kit-1.0`` (layout / formula / OCR models) and ``hantian/layoutreader`` with

@@ -1,4 +1,4 @@
-"""rocprofv3 wrapper (SURVEY 5.1): per-kernel time plus hardware counters for any script of this repository.
+"""rocprofv3 wrapper: per-kernel time plus hardware counters for any script of this repository.
 
     python -m distributed_llms_amd.tools.profile --out profiles/10_bench -- bench.py --steps 2 --warmup 1
     python -m distributed_llms_amd.tools.profile --passes time,mfma,lds --out profiles/x -- bench/kernel_bench.py

@@ -1,4 +1,4 @@
-"""Synthetic line-crop dataset for recognizer training (BASELINE config 5).
+"""Synthetic line-crop dataset for recognizer training.
 
 Rendered on the host with PIL (``pdf.synth.render_line``), resized to the
 recognizer height, normalised to [-1, 1] and padded to a fixed bucket width so

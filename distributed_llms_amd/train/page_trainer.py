@@ -1,4 +1,4 @@
-"""Teach the detector and recognizer to read synthetic scanned pages (SURVEY 4, 5.4).
+"""Teach the detector and recognizer to read synthetic scanned pages.
 
 No dataset or checkpoint is reachable offline, so the only way to show that upload -> detect -> crop ->
 recognise -> decode really produces the text on the page is to train both models on generated pages and evaluate

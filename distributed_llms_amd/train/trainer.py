@@ -1,14 +1,14 @@
-"""Recognizer training: CTC on synthetic line crops, data-parallel over RCCL (BASELINE config 5).
+"""Recognizer training: CTC on synthetic line crops, data-parallel over RCCL.
 
-The reference has no training code (SURVEY 2D, 5.4); this subsystem exists so the
+The reference has no training code; this subsystem exists so the
 random-init recognizer can actually be taught, and to exercise the training-side
 MI355X pieces end to end:
 
 * forward/backward through the model's PyTorch path under bf16 autocast,
-* ``ops.ctc_loss``   - fused CTC forward + gradient HIP kernel (N14),
+* ``ops.ctc_loss``   - fused CTC forward + gradient HIP kernel,
 * ``parallel.ddp``   - flat buckets, all-reduce (or reduce-scatter + all-gather)
-  over RCCL/xGMI launched from autograd hooks so it overlaps backward (N15),
-* ``ops.optim``      - one fused AdamW launch per bucket, clipping folded in (N16),
+  over RCCL/xGMI launched from autograd hooks so it overlaps backward,
+* ``ops.optim``      - one fused AdamW launch per bucket, clipping folded in,
 * checkpoints        - safetensors weights + optimizer moments + step/RNG, atomic
   rename, written by rank 0 (rank-local files for sharded optimizer state).
 """
@@ -149,7 +149,7 @@ class CTCTrainer:
         self.model.train()
         return {"exact": n_ok / max(n_tot, 1), "char_acc": ch_ok / max(ch_tot, 1)}
 
-    # ------------------------------------------------------------------ checkpoint / resume (SURVEY 5.4)
+    # ------------------------------------------------------------------ checkpoint / resume
     def save_checkpoint(self, directory: str) -> Optional[Path]:
         from safetensors.torch import save_file
 

@@ -16,7 +16,7 @@ a GPU box (nothing is JIT-compiled at import time).  ``hipcc`` cross-compiles
 without a GPU, so ``build_all()`` is also the CPU-side "does it build" check
 used by ``__graft_entry__.build``.
 
-The reference has no native code of its own (SURVEY.md 2C); these libraries
+The reference has no native code of its own; these libraries
 replace the wheels it pulls in (PyMuPDF, OpenCV, pyclipper, torch-CPU ops).
 """
 from __future__ import annotations

@@ -1,4 +1,4 @@
-"""Prometheus metrics (SURVEY 5.5): documents, pages, per-stage latency, queue depth, batch fill,
+"""Prometheus metrics: documents, pages, per-stage latency, queue depth, batch fill,
 per-GPU memory.  The reference exposes no application metrics at all (only host metrics through
 the CloudWatch agent, terraform/cloudwatch-agent-config.json); ``GET /metrics`` is new."""
 from __future__ import annotations

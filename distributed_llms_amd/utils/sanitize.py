@@ -1,4 +1,4 @@
-"""Debug build target: host C++ under AddressSanitizer + UBSan (SURVEY 5.2).
+"""Debug build target: host C++ under AddressSanitizer + UBSan.
 
 Builds ``csrc/tests/sanitize_main.cpp`` together with the PDF reader, batcher and BPE sources into
 ``build/sanitize/dlamd_san`` (``-fsanitize=address,undefined``, runtimes linked statically so a preloaded

@@ -1,4 +1,4 @@
-"""Model weight files: safetensors in, safetensors out (SURVEY 5.4, R15).
+"""Model weight files: safetensors in, safetensors out.
 
 The reference downloads third-party checkpoints at image-build time
 (services/ocr_service/download_models_hf.py:36-51).  There is no network here, so

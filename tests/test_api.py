@@ -1,4 +1,4 @@
-"""API contract tests (one test per row of the reference's API.md) against the ASGI app with
+"""API contract tests against the ASGI app with
 in-memory stores.  The CPU extractor runs the real pipeline: text PDFs through the native reader,
 scanned PDFs through tiny DBNet/CRNN models on the CPU oracle path."""
 import json
@@ -85,13 +85,13 @@ def test_extract_text_pdf_end_to_end(ctx):
         body = r.json()
         assert set(body) == {"document_id", "text", "status"} and body["status"] == "completed"
         assert body["text"].startswith("The quick brown fox") and "Page two has a single line" in body["text"]
-        assert "\n\n" in body["text"]  # content-list items are joined with blank lines (SURVEY 2B-7)
-    # Mongo "checkpoint format": exactly six fields with the reference's types (2B-8)
+        assert "\n\n" in body["text"]  # content-list items are joined with blank lines
+    # Mongo "checkpoint format": exactly six fields with the reference's types
     doc = results.find("doc-1")
     assert set(doc) == {"document_id", "combined_text", "status", "processed_at", "word_count", "character_count"}
     assert doc["status"] == "completed" and doc["word_count"] == len(doc["combined_text"].split())
     assert doc["character_count"] == len(doc["combined_text"])
-    # final Redis value holds the full text, the hash, no preview (2B-2); hash key points at the id
+    # final Redis value holds the full text, the hash, no preview; hash key points at the id
     st = status.get("doc-1")
     assert st["status"] == "completed" and st["result"] == doc["combined_text"] and "result_preview" not in st
     assert status.document_for_hash(st["document_hash"]) == "doc-1"
@@ -209,7 +209,7 @@ def test_health_states(ctx):
 
 
 def test_write_order_result_row_exists_before_completed(ctx):
-    """2B-2: the result store is written before any status says 'completed'."""
+    """The result store is written before any status says 'completed'."""
     settings, status, results = ctx
     seen = []
     orig = status.update

@@ -1,4 +1,4 @@
-"""Direct all-reduce over HIP IPC peer buffers (parallel/direct.py, csrc/kernels/direct_allreduce.hip; SURVEY 5.8).
+"""Direct all-reduce over HIP IPC peer buffers (parallel/direct.py, csrc/kernels/direct_allreduce.hip).
 
 The GPU tests run N ranks as N processes that all use cuda:0 (the test box has one GPU): buffers still
 travel through hipIpcGetMemHandle / hipIpcOpenMemHandle and the kernels of different processes

@@ -1,4 +1,4 @@
-"""Native PDF reader: structure variants, text operators, encodings, images, classifier, JPEG scan (SURVEY N1)."""
+"""Native PDF reader: structure variants, text operators, encodings, images, classifier, JPEG scan."""
 import io
 import zlib
 

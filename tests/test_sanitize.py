@@ -1,4 +1,4 @@
-"""Host C++ (PDF reader, JPEG scanner, batcher, BPE vocabulary) under ASan + UBSan on mutated inputs (SURVEY 5.2)."""
+"""Host C++ (PDF reader, JPEG scanner, batcher, BPE vocabulary) under ASan + UBSan on mutated inputs."""
 import shutil
 
 import pytest

@@ -1,4 +1,4 @@
-"""Status / result stores, RESP client against the in-process fake server, config, multipart (SURVEY 4 unit list)."""
+"""Status / result stores, RESP client against the in-process fake server, config, multipart."""
 import json
 import os
 

@@ -1,4 +1,4 @@
-"""Data-parallel training over a 2-rank gloo group on CPU (SURVEY 4 'distributed without a cluster'):
+"""Data-parallel training over a 2-rank gloo group on CPU:
 bitwise DP=2-with-identical-shards == DP=1, bucketed all-reduce vs reduce-scatter/all-gather with a
 sharded optimizer, checkpoint / resume."""
 import os
@@ -46,7 +46,8 @@ def _run_rank(rank, world, port, mode, out_dir, identical):
             else:
                 batch = tr.synthetic_batch(step)                               # rank-specific slice of the global batch
             losses.append(tr.train_step(*batch))
-        flat = torch.cat([b.flat_param for b in tr.ddp.flat.buckets])
+        # parameter values in model order (bucket padding depends on the world size, the parameters do not)
+        flat = torch.cat([p.detach().reshape(-1) for p in tr.model.parameters()])
         torch.save({"flat": flat, "losses": losses, "comm_calls": tr.ddp.comm_calls}, os.path.join(out_dir, f"r{rank}.pt"))
         tr.save_checkpoint(os.path.join(out_dir, "ckpt"))
         dist.barrier()
@@ -75,7 +76,7 @@ def _single(identical, world=2):
             batch = (torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts]),
                      torch.cat([p[2] for p in parts]), torch.cat([p[3] for p in parts]))
         losses.append(tr.train_step(*batch))
-    return torch.cat([b.flat_param for b in tr.ddp.flat.buckets]), losses
+    return torch.cat([p.detach().reshape(-1) for p in tr.model.parameters()]), losses
 
 
 @pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])

@@ -1,4 +1,4 @@
-"""The recognizer can be taught (SURVEY 4): overfit a tiny set of strings with the CTC trainer, then read the same
+"""The recognizer can be taught: overfit a tiny set of strings with the CTC trainer, then read the same
 lines back through the *inference* path (NHWC bf16 fused convs -> LSTM -> CTC greedy decode)."""
 import numpy as np
 import torch

@@ -153,7 +153,7 @@ def _engine_pages(n=3):
 
 
 def test_engine_runs_with_the_transformer_recognizer_cpu():
-    """OCR_RECOGNIZER=trocr (SURVEY 5.6): the engine crops to S x S, runs encoder + greedy decoder, decodes tokens
+    """OCR_RECOGNIZER=trocr: the engine crops to S x S, runs encoder + greedy decoder, decodes tokens
     with the native byte-level vocabulary, and is deterministic."""
     from distributed_llms_amd.runtime.workers import build_engine
 

@@ -1,4 +1,4 @@
-"""Worker pool on CPU: page sharding over 2 worker processes, ordered gather, dead-worker recovery (SURVEY 4, 5.3)."""
+"""Worker pool on CPU: page sharding over 2 worker processes, ordered gather, dead-worker recovery."""
 import time
 
 import numpy as np
