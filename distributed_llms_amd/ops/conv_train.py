@@ -1,0 +1,93 @@
+"""Convolution for TRAINING on the in-repo kernels: forward, data gradient and weight gradient of an NHWC bf16
+convolution as one ``torch.autograd.Function``.
+
+* forward  = ``ops.conv.conv2d_nhwc`` (the inference kernels; no bias, no activation);
+* data gradient = the same forward kernels with the operands re-indexed: the filter turned by 180 degrees with its
+  channel axes swapped, applied with stride 1 to the output gradient - for a strided convolution the gradient is
+  first spread onto the input grid (zeros between the samples) inside a buffer that already holds the padding;
+* weight gradient = ``csrc/kernels/conv_wgrad.hip`` (split-K MFMA kernel; both operands read from LDS through the
+  transposed read, fp32 atomics).
+
+The reference has no training code; there is nothing to cite.  Layers outside the kernels' shape contract (Cin or Cout
+not a multiple of 64, kernels larger than 3 x 3, horizontal stride above 2) and CPU tensors take PyTorch's own
+convolution, so the Function is safe to use for every layer of a model.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import _loader
+from . import conv as C
+
+
+def wgrad_serves(cin: int, cout: int, kh: int, kw: int, sh: int, sw: int) -> bool:
+    return cin % 64 == 0 and cout % 64 == 0 and 1 <= kh <= 3 and 1 <= kw <= 3 and 1 <= sw <= 2 and 1 <= sh <= 4
+
+
+def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int, stride: Tuple[int, int], padding: Tuple[int, int]
+               ) -> torch.Tensor:
+    """x: [N,H,W,Cin] bf16, dy: [N,Ho,Wo,Cout] bf16 -> dW [Cout,kh,kw,Cin] fp32."""
+    N, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    (sh, sw), (ph, pw) = stride, padding
+    if not x.is_cuda or not wgrad_serves(Cin, Cout, kh, kw, sh, sw):
+        xf = x.float().permute(0, 3, 1, 2)
+        dyf = dy.float().permute(0, 3, 1, 2)
+        dw = torch.nn.grad.conv2d_weight(xf, (Cout, Cin, kh, kw), dyf, stride=stride, padding=padding)
+        return dw.permute(0, 2, 3, 1).contiguous()
+    assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and x.is_contiguous() and dy.is_contiguous()
+    assert tuple(dy.shape[:3]) == (N, (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1)
+    dw = torch.zeros((Cout, kh, kw, Cin), dtype=torch.float32, device=x.device)
+    rc = _loader.lib().dlamd_conv_wgrad(_loader.ptr(x), _loader.ptr(dy), _loader.ptr(dw), N, H, W, Cin, Cout, kh, kw,
+                                        sh, sw, ph, pw, _loader.stream_ptr())
+    _loader.check(rc, "dlamd_conv_wgrad")
+    return dw
+
+
+def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, in_hw: Tuple[int, int], stride: Tuple[int, int],
+               padding: Tuple[int, int]) -> torch.Tensor:
+    """dy: [N,Ho,Wo,Cout] bf16, w: [Cout,kh,kw,Cin] bf16 -> dX [N,H,W,Cin] bf16 through the forward kernels."""
+    N, Ho, Wo, Cout = dy.shape
+    _, kh, kw, Cin = w.shape
+    (sh, sw), (ph, pw), (H, W) = stride, padding, in_hw
+    # filter for the gradient: [Cin, kh, kw, Cout], taps turned by 180 degrees
+    wt = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()
+    if sh == 1 and sw == 1 and kh - 1 - ph >= 0 and kw - 1 - pw >= 0 and H == Ho + kh - 1 - 2 * ph and W == Wo + kw - 1 - 2 * pw:
+        return C.conv2d_nhwc(dy, wt, None, stride=1, padding=(kh - 1 - ph, kw - 1 - pw))
+    # general case: gradient samples placed on the padded input grid, then a VALID stride-1 convolution
+    buf = torch.zeros((N, H + kh - 1, W + kw - 1, Cout), dtype=dy.dtype, device=dy.device)
+    oy0, ox0 = kh - 1 - ph, kw - 1 - pw
+    assert oy0 >= 0 and ox0 >= 0, "padding larger than the kernel is not supported"
+    buf[:, oy0 : oy0 + (Ho - 1) * sh + 1 : sh, ox0 : ox0 + (Wo - 1) * sw + 1 : sw] = dy
+    return C.conv2d_nhwc(buf, wt, None, stride=1, padding=0)
+
+
+class _ConvNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, stride, padding):
+        # x: [N,H,W,Cin] bf16; weight: [Cout,Cin,kh,kw] (the nn.Conv2d parameter, any float dtype)
+        w = weight.detach().permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.stride, ctx.padding, ctx.wdtype = stride, padding, weight.dtype
+        return C.conv2d_nhwc(x, w, None, stride=stride, padding=padding)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = conv_dgrad(dy, w, (x.shape[1], x.shape[2]), ctx.stride, ctx.padding)
+        if ctx.needs_input_grad[1]:
+            dw = conv_wgrad(x, dy, w.shape[1], w.shape[2], ctx.stride, ctx.padding).permute(0, 3, 1, 2).to(ctx.wdtype)
+        return dx, dw, None, None
+
+
+def conv2d_nhwc_train(x: torch.Tensor, weight: torch.Tensor, stride=(1, 1), padding=(0, 0)) -> torch.Tensor:
+    """Differentiable NHWC bf16 convolution.  x: [N,H,W,Cin] bf16 (Cin a multiple of 8), weight: [Cout,Cin,kh,kw]."""
+    stride = (stride, stride) if isinstance(stride, int) else tuple(stride)
+    padding = (padding, padding) if isinstance(padding, int) else tuple(padding)
+    return _ConvNHWC.apply(x.contiguous(), weight, stride, padding)

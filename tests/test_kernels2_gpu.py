@@ -431,3 +431,44 @@ def test_row_cumsum_matches_torch_for_ragged_lengths():
         out = torch.empty_like(x)
         assert torch.equal(row_cumsum_i32(x, out), want), (rows, n)
         assert torch.equal(row_cumsum_i32(x, out, exclusive=True), want - x), (rows, n)
+
+
+CONV_TRAIN_CASES = [
+    # Cin, Cout, (kh, kw), stride, padding, N, H, W
+    (64, 64, (3, 3), (1, 1), (1, 1), 2, 9, 11),
+    (64, 128, (3, 3), (2, 2), (1, 1), 3, 24, 70),        # CRNN c2: stride 2, ragged last 32-pixel unit
+    (128, 256, (3, 3), (1, 1), (1, 1), 2, 12, 45),
+    (256, 256, (3, 3), (2, 1), (1, 1), 2, 12, 37),       # stride (2, 1)
+    (256, 512, (3, 3), (2, 1), (1, 1), 1, 6, 33),
+    (512, 512, (3, 1), (1, 1), (0, 0), 2, 3, 40),        # 3 x 1 valid convolution
+    (8, 64, (3, 3), (2, 2), (1, 1), 2, 16, 20),          # outside the wgrad contract: PyTorch's weight gradient
+]
+
+
+@pytest.mark.parametrize("case", CONV_TRAIN_CASES)
+def test_conv_train_function_matches_autograd(case):
+    """Forward, data gradient (forward kernels on re-indexed operands) and weight gradient (transposed-LDS-read MFMA
+    kernel, split-K atomics) of the training convolution against PyTorch autograd in fp32 on the same bf16 values."""
+    from distributed_llms_amd.ops.conv_train import conv2d_nhwc_train
+
+    Cin, Cout, k, s, p, N, H, W = case
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    x = torch.randn(N, H, W, Cin, generator=g).to(torch.bfloat16)
+    w = (torch.randn(Cout, Cin, *k, generator=g) * (2.0 / (Cin * k[0] * k[1])) ** 0.5)
+    xd = x.to(DEV).requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True)
+    y = conv2d_nhwc_train(xd, wd, s, p)
+    gy = torch.randn(y.shape, generator=g).to(torch.bfloat16)
+    y.backward(gy.to(DEV))
+    x2 = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    w2 = w.to(torch.bfloat16).float().requires_grad_(True)
+    y2 = torch.nn.functional.conv2d(x2, w2, None, s, p)
+    y2.backward(gy.float().permute(0, 3, 1, 2))
+    assert tuple(y.shape) == (N, y2.shape[2], y2.shape[3], Cout)
+
+    def rel(a, b):
+        return (a.float().cpu() - b).abs().max().item() / max(b.abs().max().item(), 1e-6)
+
+    assert rel(y, y2.permute(0, 2, 3, 1)) < 1e-2
+    assert rel(xd.grad, x2.grad.permute(0, 2, 3, 1)) < 1.5e-2          # bf16 output of a K = 9 Cout reduction
+    assert wd.grad.dtype == torch.float32 and rel(wd.grad, w2.grad) < 2e-3
