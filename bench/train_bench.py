@@ -31,12 +31,13 @@ def main():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--mode", default="allreduce", choices=["allreduce", "rs_ag", "direct"])
     ap.add_argument("--bucket-mb", type=float, default=64.0)
+    ap.add_argument("--library-convs", action="store_true", help="convolutions through the library (MIOpen) instead of the in-repo training kernels (ops/conv_train.py)")
     ap.add_argument("--cpu", action="store_true")
     ap.add_argument("--distinct", type=int, default=4, help="pre-rendered batches cycled through")
     args = ap.parse_args()
     env = comm.init_distributed(force_cpu=args.cpu)
     cfg = TrainConfig(batch_size=args.batch, width=args.width, dp_mode=args.mode, bucket_mb=args.bucket_mb,
-                      max_chars=max(8, args.width // 22))
+                      max_chars=max(8, args.width // 22), own_convs=not args.library_convs)
     torch.manual_seed(0)
     model = CRNN() if env.device.type == "cuda" else CRNN(hidden=64, widths=(16, 32, 32, 32, 64, 64))
     tr = CTCTrainer(model, cfg, env.device, env)
@@ -66,7 +67,7 @@ def main():
             "allreduce_wait_ms_per_step": round(1e3 * tr.comm_time / args.steps, 3),
             "grad_bytes_per_step": n_params * 4, "buckets": len(tr.ddp.flat.buckets), "dp_mode": args.mode,
             "final_loss": round(loss, 4), "dtype": "bf16 autocast, fp32 master" if env.device.type == "cuda" else "fp32",
-            "config": {"model": "CRNN", "params": n_params, "per_gpu_batch": args.batch, "width": args.width,
+            "config": {"model": "CRNN", "convolutions": "library (MIOpen)" if args.library_convs or env.device.type != "cuda" else "in-repo kernels (ops/conv_train.py)", "params": n_params, "per_gpu_batch": args.batch, "width": args.width,
                        "global_batch": args.batch * env.world, "seq_len": args.width // 4,
                        "parallelism": f"dp{env.world}"},
         }), flush=True)

@@ -6,10 +6,10 @@
 // (`ds_read_b64_tr_b16`: a 16-lane group fetches 4 rows x 16 columns and every lane receives one column).
 //
 // A workgroup owns dW[64 output channels][all taps][64 input channels] (up to 9 taps: 36 accumulator tiles per wave)
-// and walks over units of 32 consecutive output pixels of one output row:
-//   * the dY tile [32][64] and the input patch under it ([kh][31 * sw + kw][64], zero outside the image) are fetched
+// and walks over units of 64 consecutive output pixels of one output row (two MFMA K-steps per barrier pair):
+//   * the dY tile [64][64] and the input patch under it ([kh][63 * sw + kw][64], zero outside the image) are fetched
 //     into registers one unit ahead and written to LDS after the previous unit's MFMAs;
-//   * wave w takes input channels 16 w .. 16 w + 15: per unit it reads 4 dY fragments (one per 16 output channels) and
+//   * wave w takes input channels 16 w .. 16 w + 15: per K-step it reads 4 dY fragments (one per 16 output channels) and
 //     one patch fragment per tap - 13 fragments for 36 MFMAs, so the LDS port stays below the MFMA time;
 //   * units are spread over gridDim.x workgroups (split-K); partial sums are added to dW with float atomics, so the
 //     caller zero-fills dW first.
@@ -24,13 +24,13 @@ struct WgradArgs {
   float* dw;           // [Cout, kh, kw, Cin], accumulated into
   int N, H, W, Cin, Ho, Wo, Cout;
   int kh, kw, sh, sw, ph, pw;
-  int segs;            // ceil(Wo / 32)
+  int segs;            // ceil(Wo / WG_PX)
   long long units;     // N * Ho * segs
 };
 
-static constexpr int WG_PX = 32;            // output pixels per unit (one MFMA K-step)
+static constexpr int WG_PX = 64;            // output pixels per unit (two MFMA K-steps per barrier pair)
 static constexpr int WG_PITCH = 64 * 2 + 16;  // bytes per pixel row of an LDS tile (64 channels + pad: bank spread)
-static constexpr int WG_MAX_PW = 31 * 2 + 3;  // widest patch row (stride 2, 3 taps)
+static constexpr int WG_MAX_PW = (WG_PX - 1) * 2 + 3;  // widest patch row (stride 2, 3 taps)
 static constexpr int WG_MAX_LOADS = (3 * WG_MAX_PW * 8 + 255) / 256;   // 16-byte patch chunks per thread
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int row0, int row_step, int col0, int lane) {
@@ -61,17 +61,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  u32x4 rdy, rx[WG_MAX_LOADS];
+  constexpr int DY_LOADS = WG_PX * 8 / 256;
+  u32x4 rdy[DY_LOADS], rx[WG_MAX_LOADS];
   auto fetch = [&](long long u) {
     const int seg = (int)(u % p.segs);
     const long long r = u / p.segs;
     const int oy = (int)(r % p.Ho), n = (int)(r / p.Ho);
     const int ox0 = seg * WG_PX;
-    {   // dY tile: pixel tid / 8, 16-byte chunk tid % 8
-      const int px = tid >> 3, ch = tid & 7, ox = ox0 + px;
-      rdy = zero;
+#pragma unroll
+    for (int i = 0; i < DY_LOADS; ++i) {   // dY tile: pixel e / 8, 16-byte chunk e % 8
+      const int e = i * 256 + tid, px = e >> 3, ch = e & 7, ox = ox0 + px;
+      rdy[i] = zero;
       if (ox < p.Wo)
-        rdy = *reinterpret_cast<const u32x4*>(p.dy + (((long long)n * p.Ho + oy) * p.Wo + ox) * p.Cout + co0 + ch * 8);
+        rdy[i] = *reinterpret_cast<const u32x4*>(p.dy + (((long long)n * p.Ho + oy) * p.Wo + ox) * p.Cout + co0 + ch * 8);
     }
 #pragma unroll
     for (int i = 0; i < WG_MAX_LOADS; ++i) {
@@ -87,7 +89,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     }
   };
   auto stash = [&]() {
-    *reinterpret_cast<u32x4*>(dys + (tid >> 3) * WG_PITCH + (tid & 7) * 16) = rdy;
+#pragma unroll
+    for (int i = 0; i < DY_LOADS; ++i) {
+      const int e = i * 256 + tid;
+      *reinterpret_cast<u32x4*>(dys + (e >> 3) * WG_PITCH + (e & 7) * 16) = rdy[i];
+    }
 #pragma unroll
     for (int i = 0; i < WG_MAX_LOADS; ++i) {
       const int e = i * 256 + tid;
@@ -103,18 +109,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     __syncthreads();
     const long long un = u + gridDim.x;
     if (un < p.units) fetch(un);   // in flight under the MFMAs below
-    bf16x8 a[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = tr_frag(dys, 0, 1, i * 16, lane);
+    for (int ks = 0; ks < WG_PX / 32; ++ks) {
+      bf16x8 a[4];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      // every lane executes the transposed read (it needs the whole wave); taps beyond kh * kw read tap 0 and are dropped
-      const int tt = t < taps ? t : 0;
-      const int r = tt / p.kw, s = tt - r * p.kw;
-      const bf16x8 b = tr_frag(xs, r * PW + s, p.sw, wave * 16, lane);
-      if (t < taps) {
+      for (int i = 0; i < 4; ++i) a[i] = tr_frag(dys, 32 * ks, 1, i * 16, lane);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][t], 0, 0, 0);
+      for (int t = 0; t < 9; ++t) {
+        // every lane executes the transposed read (it needs the whole wave); taps beyond kh * kw read tap 0 and are dropped
+        const int tt = t < taps ? t : 0;
+        const int r = tt / p.kw, s = tt - r * p.kw;
+        const bf16x8 b = tr_frag(xs, r * PW + s + 32 * ks * p.sw, p.sw, wave * 16, lane);
+        if (t < taps) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][t], 0, 0, 0);
+        }
       }
     }
     u = un;

@@ -26,6 +26,7 @@ import torch.nn as nn
 
 from ..ops import ctc as ctc_ops
 from ..ops import lstm as lstm_ops
+from ..ops.conv import _act_ref as C_act
 from ..ops.conv import linear_bf16
 from .layers import ConvBNAct, prepare_all
 
@@ -60,6 +61,9 @@ class CRNN(nn.Module):
         self.fc = nn.Linear(2 * hidden, self.num_classes)
         self._packed = None
         self.fused_train_lstm = hidden in (64, 128, 256)   # device tensors: HIP recurrence kernels in forward()
+        # training on the in-repo convolution kernels (ops/conv_train.py: forward, data and weight gradient) instead of
+        # the library's; set by the trainers (TrainConfig.own_convs)
+        self.own_conv_train = False
 
     # ------------------------------------------------------------------ character set follows the weights
     def set_charset(self, charset: str) -> None:
@@ -101,10 +105,13 @@ class CRNN(nn.Module):
     # ------------------------------------------------------------------ training path
     def forward(self, x: torch.Tensor, lens: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x: [N,3,48,W] -> logits [N, T, num_classes] (fp32)."""
-        y = x
-        for c in self.convs:
-            y = c(y)
-        y = y.squeeze(2).transpose(1, 2)  # [N, T, C]
+        if x.is_cuda and self.own_conv_train and self.training:
+            y = self._conv_stack_own_kernels(x)            # [N, T, C]
+        else:
+            y = x
+            for c in self.convs:
+                y = c(y)
+            y = y.squeeze(2).transpose(1, 2)  # [N, T, C]
         if y.is_cuda and self.fused_train_lstm:
             # persistent HIP recurrences (ops/lstm_train.py): 2 launches per layer and direction pair instead of
             # one GEMM + cell kernel per time step
@@ -124,6 +131,22 @@ class CRNN(nn.Module):
             y, _ = self.rnn1(y)
             y, _ = self.rnn2(y)
         return self.fc(y)
+
+    def _conv_stack_own_kernels(self, x: torch.Tensor) -> torch.Tensor:
+        """The convolution stack in NHWC bf16 on the in-repo kernels (``ops.conv_train``): the 3-channel first layer
+        stays with PyTorch (its weight gradient is outside the kernel's shape contract and it is 2 % of the FLOPs),
+        batch norm runs on the channels-last view of each result, so no layout copies sit between the layers."""
+        from ..ops.conv_train import conv2d_nhwc_train
+
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = self.convs[0](x.contiguous(memory_format=torch.channels_last))
+        y = y.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()           # NHWC
+        for c in self.convs[1:]:
+            assert c.conv.bias is None and c.bn is not None
+            z = conv2d_nhwc_train(y, c.conv.weight, c.stride, c.padding)
+            zn = c.bn(z.permute(0, 3, 1, 2))                                  # NCHW view of NHWC memory (channels last)
+            y = C_act(zn, c.act).to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()
+        return y.squeeze(1)                                                  # [N, 1, T, C] -> [N, T, C]
 
     # ------------------------------------------------------------------ inference path
     def prepare(self) -> "CRNN":

@@ -52,6 +52,7 @@ class TrainConfig:
     ckpt_dir: Optional[str] = None
     ckpt_every: int = 0
     log_every: int = 10
+    own_convs: bool = True        # convolutions (forward, dgrad, wgrad) on the in-repo kernels (ops/conv_train.py); GPU only
 
 
 class CTCTrainer:
@@ -63,6 +64,8 @@ class CTCTrainer:
         torch.manual_seed(cfg.seed)
         self.model = model.to(self.device).float()
         self.model.train()
+        if cfg.own_convs and hasattr(self.model, "own_conv_train"):
+            self.model.own_conv_train = self.device.type == "cuda"
         self.ddp = BucketedDDP(self.model, cfg.bucket_mb, cfg.dp_mode)
         flats = [(b.flat_param, b.flat_grad) for b in self.ddp.flat.buckets]
         # unsharded: update exactly the occupied prefix (the padding depends on the world size; keeping it out
