@@ -425,6 +425,8 @@ def main(argv=None) -> int:
     ap.add_argument("--time-limit", type=float, default=900.0, help="stop cleanly (and save) after this many seconds")
     ap.add_argument("--threads", type=int, default=12)
     ap.add_argument("--init", default="", help="directory with weights to start from (step count restarts at 0)")
+    ap.add_argument("--library-convs", action="store_true",
+                    help="recogniser convolutions through the library instead of the in-repo training kernels (ops/conv_train.py)")
     args = ap.parse_args(argv)
     device = torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
     torch.manual_seed(0)
@@ -457,6 +459,7 @@ def main(argv=None) -> int:
         print(f"character set grown from {n_old} to {len(rec.charset)} characters", flush=True)
     det.train()
     rec.train()
+    rec.own_conv_train = device.type == "cuda" and not args.library_convs
     dopt, ropt = _Opt(det, args.det_lr), _Opt(rec, args.rec_lr)
     it = start
     prod = PageProducer(device, threads=args.threads)

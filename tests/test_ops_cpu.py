@@ -150,3 +150,40 @@ def test_lstm_reference_matches_nn_lstm_and_packing_roundtrip():
     torch.testing.assert_close(
         p.w_frag[0].float().sum(), m.weight_hh_l0.detach().to(torch.bfloat16).float().sum(), rtol=1e-3, atol=1e-2
     )
+
+
+def test_training_convolution_function_on_cpu_matches_autograd():
+    """ops/conv_train.py off the GPU: the data gradient is still formed the kernels' way (180-degree-turned filter,
+    gradient samples spread on the padded input grid for strided layers), so its arithmetic is checked here."""
+    import torch
+
+    from distributed_llms_amd.ops.conv_train import conv2d_nhwc_train
+
+    g = torch.Generator().manual_seed(0)
+    for cin, cout, k, s, p, H, W in ((16, 8, (3, 3), (1, 1), (1, 1), 7, 9), (8, 16, (3, 3), (2, 2), (1, 1), 10, 13),
+                                     (8, 8, (3, 3), (2, 1), (1, 1), 9, 12), (16, 16, (3, 1), (1, 1), (0, 0), 3, 10),
+                                     (8, 8, (1, 1), (2, 2), (0, 0), 6, 7)):
+        x = torch.randn(2, H, W, cin, generator=g).to(torch.bfloat16).requires_grad_(True)
+        w = (torch.randn(cout, cin, *k, generator=g) * 0.1).requires_grad_(True)
+        y = conv2d_nhwc_train(x, w, s, p)
+        gy = torch.randn(y.shape, generator=g).to(torch.bfloat16)
+        y.backward(gy)
+        x2 = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
+        w2 = w.detach().to(torch.bfloat16).float().requires_grad_(True)
+        y2 = torch.nn.functional.conv2d(x2, w2, None, s, p)
+        y2.backward(gy.float().permute(0, 3, 1, 2))
+        rel = lambda a, b: (a.float() - b).abs().max().item() / max(b.abs().max().item(), 1e-6)   # noqa: E731
+        assert rel(y, y2.permute(0, 2, 3, 1)) < 1e-2
+        assert rel(x.grad, x2.grad.permute(0, 2, 3, 1)) < 1e-2
+        assert rel(w.grad, w2.grad) < 1e-4
+
+
+def test_row_cumsum_cpu_path():
+    import torch
+
+    from distributed_llms_amd.ops.scan import row_cumsum_i32
+
+    x = torch.randint(-50, 50, (3, 1030), dtype=torch.int32)
+    out = torch.empty_like(x)
+    assert torch.equal(row_cumsum_i32(x, out), torch.cumsum(x, 1, dtype=torch.int32))
+    assert torch.equal(row_cumsum_i32(x, out, exclusive=True), torch.cumsum(x, 1, dtype=torch.int32) - x)
