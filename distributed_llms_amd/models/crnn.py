@@ -26,7 +26,6 @@ import torch.nn as nn
 
 from ..ops import ctc as ctc_ops
 from ..ops import lstm as lstm_ops
-from ..ops.conv import _act_ref as C_act
 from ..ops.conv import linear_bf16
 from .layers import ConvBNAct, prepare_all
 
@@ -134,18 +133,19 @@ class CRNN(nn.Module):
 
     def _conv_stack_own_kernels(self, x: torch.Tensor) -> torch.Tensor:
         """The convolution stack in NHWC bf16 on the in-repo kernels (``ops.conv_train``): the 3-channel first layer
-        stays with PyTorch (its weight gradient is outside the kernel's shape contract and it is 2 % of the FLOPs),
-        batch norm runs on the channels-last view of each result, so no layout copies sit between the layers."""
-        from ..ops.conv_train import conv2d_nhwc_train
+        runs forward on the stem kernel and takes its weight gradient from an im2col of the image times the output
+        gradient (``ops.conv_train.conv2d_first_layer_train``), batch norm + ReLU are one in-repo Function on the NHWC
+        result (``ops.bn_train``), so no layout copies sit between the layers."""
+        from ..ops.bn_train import bn_act_train
+        from ..ops.conv_train import conv2d_first_layer_train, conv2d_nhwc_train
 
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            y = self.convs[0](x.contiguous(memory_format=torch.channels_last))
-        y = y.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()           # NHWC
+        c0 = self.convs[0]
+        assert c0.conv.bias is None and c0.bn is not None
+        y = bn_act_train(conv2d_first_layer_train(x, c0.conv.weight, c0.stride, c0.padding), c0.bn, c0.act)
         for c in self.convs[1:]:
             assert c.conv.bias is None and c.bn is not None
             z = conv2d_nhwc_train(y, c.conv.weight, c.stride, c.padding)
-            zn = c.bn(z.permute(0, 3, 1, 2))                                  # NCHW view of NHWC memory (channels last)
-            y = C_act(zn, c.act).to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()
+            y = bn_act_train(z, c.bn, c.act)                                  # batch statistics + ReLU, one Function
         return y.squeeze(1)                                                  # [N, 1, T, C] -> [N, T, C]
 
     # ------------------------------------------------------------------ inference path

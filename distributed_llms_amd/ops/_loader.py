@@ -102,6 +102,8 @@ def _declare(l: ctypes.CDLL) -> None:
     sig("dlamd_jpeg_sync_finish", [vp, vp, i, ll, ll, vp])
     sig("dlamd_row_cumsum_i32", [vp, vp, vp, ll, i, i, i, vp])
     sig("dlamd_conv_wgrad", [vp, vp, vp] + [i] * 11 + [vp])
+    sig("dlamd_bn_train_fwd", [vp] * 10 + [ll, i, f, f, i, vp])
+    sig("dlamd_bn_train_bwd", [vp] * 9 + [ll, i, i, vp])
     sig("dlamd_lstm_train_fwd", [vp, vp, vp, vp, vp, vp, i, i, i, i, vp])
     sig("dlamd_lstm_train_bwd", [vp, vp, vp, vp, vp, vp, i, i, i, i, vp])
     sig("dlamd_dar_create", [i, i, ll, i, vp])

@@ -505,3 +505,42 @@ def test_crnn_trains_on_own_convolution_kernels():
         print(f"{n}: cos {cos:.4f} norm ratio {gb[n].norm().item() / ga[n].norm().item():.3f}")
         assert cos > 0.95, (n, cos)
         assert 0.8 < gb[n].norm().item() / ga[n].norm().item() < 1.25, n
+
+
+@pytest.mark.parametrize("shape,act", [((2, 9, 37, 64), "relu"), ((3, 5, 41, 128), "relu"), ((2, 3, 50, 512), "none"),
+                                       ((1, 24, 130, 256), "relu")])
+def test_bn_relu_training_kernels_match_pytorch(shape, act):
+    """Fused batch norm (+ ReLU) forward / backward on NHWC bf16 against nn.BatchNorm2d + relu in fp32: output, running
+    statistics, and the gradients of the input, gamma and beta."""
+    from distributed_llms_amd.ops.bn_train import bn_act_train
+
+    N, H, W, C = shape
+    g = torch.Generator().manual_seed(C + W)
+    z = (torch.randn(N, H, W, C, generator=g) * 1.5 + 0.3).to(torch.bfloat16)
+    gy = torch.randn(N, H, W, C, generator=g).to(torch.bfloat16)
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.2)
+    ref = torch.nn.BatchNorm2d(C)
+    ref.load_state_dict(bn.state_dict())
+    bn = bn.to(DEV).train()
+    zd = z.to(DEV).requires_grad_(True)
+    y = bn_act_train(zd, bn, act)
+    y.backward(gy.to(DEV))
+    z2 = z.float().permute(0, 3, 1, 2).requires_grad_(True)
+    y2 = ref.train()(z2)
+    y2 = torch.relu(y2) if act == "relu" else y2
+    y2.backward(gy.float().permute(0, 3, 1, 2))
+    def close(a, b, rtol, atol):
+        err = (a.float().cpu() - b.float()).abs()
+        tol = atol + rtol * b.float().abs()
+        assert (err > tol).float().mean().item() < 1e-3 and (err / tol).max().item() < 8.0, float(err.max())
+
+    close(y, y2.permute(0, 2, 3, 1).detach(), 1e-2, 2e-2)
+    close(zd.grad, z2.grad.permute(0, 2, 3, 1), 2e-2, 2e-2 * float(z2.grad.abs().max()))
+    assert torch.allclose(bn.weight.grad.cpu(), ref.weight.grad, rtol=2e-2, atol=2e-2 * float(ref.weight.grad.abs().max()))
+    assert torch.allclose(bn.bias.grad.cpu(), ref.bias.grad, rtol=2e-2, atol=2e-2 * float(ref.bias.grad.abs().max()))
+    assert torch.allclose(bn.running_mean.cpu(), ref.running_mean, atol=1e-3)
+    assert torch.allclose(bn.running_var.cpu(), ref.running_var, rtol=1e-2, atol=1e-3)
+    assert int(bn.num_batches_tracked) == 1
