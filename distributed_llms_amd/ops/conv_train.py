@@ -88,33 +88,34 @@ class _ConvNHWC(torch.autograd.Function):
 
 class _ConvFirstLayer(torch.autograd.Function):
     """First convolution of a model: image in (no gradient wanted for it), few input channels.  Forward = the
-    inference kernels on the image padded to 8 channels; weight gradient = im2col of the image (a [N, Cin kh kw, Ho Wo]
-    tensor: small, the image has 3 channels) times the output gradient, one batched GEMM summed over the batch."""
+    inference kernels on the image padded to 8 channels; weight gradient = im2col of the padded image ([N, Ho Wo, kh kw 8]:
+    small, 16-byte pixels) times the output gradient, one batched GEMM summed over the batch."""
 
     @staticmethod
     def forward(ctx, x, weight, stride, padding):
         # x: [N, Cin, H, W] (any float dtype), weight: [Cout, Cin, kh, kw]
         cout, cin, kh, kw = weight.shape
-        xb = x.detach().to(torch.bfloat16)
-        x8 = F.pad(xb.permute(0, 2, 3, 1), (0, 8 - cin)).contiguous()
+        x8 = F.pad(x.detach().to(torch.bfloat16).permute(0, 2, 3, 1), (0, 8 - cin)).contiguous()     # NHWC, 8 channels
         w8 = F.pad(weight.detach().permute(0, 2, 3, 1), (0, 8 - cin)).to(torch.bfloat16).contiguous()
-        ctx.save_for_backward(xb)
+        ctx.save_for_backward(x8)
         ctx.meta = (stride, padding, (cout, cin, kh, kw), weight.dtype)
         return C.conv2d_nhwc(x8, w8, None, stride=stride, padding=padding)
 
     @staticmethod
     def backward(ctx, dy):
-        (xb,) = ctx.saved_tensors
+        (x8,) = ctx.saved_tensors
         stride, padding, (cout, cin, kh, kw), wdtype = ctx.meta
-        # im2col as kh * kw strided slices of the padded image (F.unfold launches one kernel per sample)
+        # im2col as kh * kw strided slices of the padded NHWC image (16-byte pixels; F.unfold launches one kernel per
+        # sample): cols[n, p, tap * 8 + c]
         (sh, sw), (ph, pw) = stride, padding
-        Ho, Wo = dy.shape[1], dy.shape[2]
-        xp = F.pad(xb, (pw, pw, ph, ph))
-        taps = [xp[:, :, r : r + sh * (Ho - 1) + 1 : sh, c : c + sw * (Wo - 1) + 1 : sw] for r in range(kh) for c in range(kw)]
-        cols = torch.stack(taps, dim=2).reshape(xb.shape[0], cin * kh * kw, Ho * Wo)   # [N, Cin kh kw, Ho Wo]
-        g = dy.reshape(dy.shape[0], -1, cout)                                   # [N, Ho Wo, Cout]
-        dw = torch.bmm(cols, g).sum(0, dtype=torch.float32)                     # [Cin kh kw, Cout]
-        return None, dw.t().reshape(cout, cin, kh, kw).to(wdtype), None, None
+        N, Ho, Wo = dy.shape[0], dy.shape[1], dy.shape[2]
+        xp = F.pad(x8, (0, 0, pw, pw, ph, ph))
+        taps = [xp[:, r : r + sh * (Ho - 1) + 1 : sh, c : c + sw * (Wo - 1) + 1 : sw] for r in range(kh) for c in range(kw)]
+        cols = torch.cat(taps, dim=3).reshape(N, Ho * Wo, kh * kw * 8)
+        g = dy.reshape(N, Ho * Wo, cout)
+        dw = torch.bmm(cols.transpose(1, 2), g).sum(0, dtype=torch.float32)     # [kh kw 8, Cout]
+        dw = dw.reshape(kh, kw, 8, cout)[:, :, :cin].permute(3, 2, 0, 1)         # [Cout, Cin, kh, kw]
+        return None, dw.contiguous().to(wdtype), None, None
 
 
 def conv2d_first_layer_train(x: torch.Tensor, weight: torch.Tensor, stride=(1, 1), padding=(0, 0)) -> torch.Tensor:
