@@ -517,12 +517,15 @@ __global__ __launch_bounds__(512) void lstm_bidir_kernel3(const bf16_t* __restri
 // is streamed per step - issued right after its use, it has the rest of the step and the next step's resident
 // MFMAs... to land.  To make room the accumulators start from the input projection (no separate copy of it is
 // alive during the MFMA phase) and the next step's projection is fetched only after the gates have retired them.
-template <int H, int KR>
+// TRAIN: additionally saves what the backward recurrence needs - the post-activation gates (bf16, layout of xproj)
+// and the cell state (fp32, layout of y) of every step.
+template <int H, int KR, bool TRAIN = false>
 __global__ __launch_bounds__(512) void lstm_bidir_kernel4(const bf16_t* __restrict__ xproj, const bf16_t* __restrict__ wfrag,
                                                           const int* __restrict__ lens,
                                                           const long long* __restrict__ row_off,
                                                           const int* __restrict__ tcap, const int* __restrict__ perm,
-                                                          bf16_t* __restrict__ y, int N, int T, int ndir) {
+                                                          bf16_t* __restrict__ y, int N, int T, int ndir,
+                                                          bf16_t* __restrict__ gact = nullptr, float* __restrict__ cbuf = nullptr) {
   constexpr int G = 4 * H;
   constexpr int NW = 8;
   constexpr int TILES = G / 16 / NW;
@@ -552,6 +555,12 @@ __global__ __launch_bounds__(512) void lstm_bidir_kernel4(const bf16_t* __restri
   const long long row0 = ok ? (row_off ? row_off[n] : (long long)n * T) : 0;
   const bf16_t* xp = xproj + row0 * xrow + (long long)dir * G + (wave * TILES) * 16 + fq * 4;
   bf16_t* yp = y + row0 * yrow + (long long)dir * H;
+  [[maybe_unused]] bf16_t* gp = nullptr;
+  [[maybe_unused]] float* cp = nullptr;
+  if constexpr (TRAIN) {
+    gp = gact + row0 * xrow + (long long)dir * G + (wave * TILES) * 16 + fq * 4;
+    cp = cbuf + row0 * yrow + (long long)dir * H;
+  }
   int maxlen = len;
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
@@ -647,6 +656,7 @@ __global__ __launch_bounds__(512) void lstm_bidir_kernel4(const bf16_t* __restri
 #pragma unroll
     for (int a = 0; a < TILES / 4; ++a) {
       bf16x4 hv;
+      [[maybe_unused]] f32x4 cv;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = a * 4 + q;
@@ -658,12 +668,19 @@ __global__ __launch_bounds__(512) void lstm_bidir_kernel4(const bf16_t* __restri
         float h = og * dl_tanh(c);
         if (act) cst[i] = c;
         hv[q] = (bf16_t)h;
+        if constexpr (TRAIN) cv[q] = c;
+        if constexpr (TRAIN) if (act) {
+          const bf16x2 p0 = {(bf16_t)ig, (bf16_t)fg}, p1 = {(bf16_t)gg, (bf16_t)og};
+          *reinterpret_cast<u32x2*>(gp + (long long)tt * xrow + i * 16) =
+              u32x2{__builtin_bit_cast(uint32_t, p0), __builtin_bit_cast(uint32_t, p1)};
+        }
       }
       const int unit = (wave * (TILES / 4) + a) * 16 + fq * 4;
       const int hoff = seq_l * HROW + unit * 2;
       if (act) {
         *reinterpret_cast<bf16x4*>(hn + hoff) = hv;
         *reinterpret_cast<bf16x4*>(yp + (long long)tt * yrow + unit) = hv;
+        if constexpr (TRAIN) *reinterpret_cast<f32x4*>(cp + (long long)tt * yrow + unit) = cv;
       } else {
         *reinterpret_cast<u32x2*>(hn + hoff) = *reinterpret_cast<const u32x2*>(hcr + hoff);
       }
@@ -690,6 +707,26 @@ __global__ __launch_bounds__(512) void lstm_bidir_kernel4(const bf16_t* __restri
   }
 }
 
+// Forward recurrence of a training step (dense [N, T] batch, H = 256) on the resident-weights kernel; called from
+// lstm_train.hip.
+int dlamd_lstm4_train_fwd(const void* xproj, const void* wfrag, const void* lens, void* y, void* gact, void* cbuf, int N, int T,
+                          int ndir, hipStream_t stream) {
+  constexpr int H = 256;
+  const size_t smem = 2 * 16 * (H * 2 + 16) + 8 * 2 * 8 * 1024;
+  auto k = lstm_bidir_kernel4<H, 4, true>;
+  static bool set = false;
+  if (!set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return -5;
+    set = true;
+  }
+  dim3 grid((N + 15) / 16, ndir);
+  hipLaunchKernelGGL(k, grid, dim3(512), smem, stream, (const bf16_t*)xproj, (const bf16_t*)wfrag, (const int*)lens,
+                     (const long long*)nullptr, (const int*)nullptr, (const int*)nullptr, (bf16_t*)y, N, T, ndir, (bf16_t*)gact,
+                     (float*)cbuf);
+  return DLAMD_CHECK_LAUNCH();
+}
+
 template <int KR>
 static int launch_lstm4(const void* xproj, const void* wfrag, const void* lens, const void* row_off, const void* tcap,
                         const void* perm, void* y, int N, int T, int ndir, hipStream_t stream) {
@@ -704,7 +741,8 @@ static int launch_lstm4(const void* xproj, const void* wfrag, const void* lens, 
   }
   dim3 grid((N + 15) / 16, ndir);
   hipLaunchKernelGGL(k, grid, dim3(512), smem, stream, (const bf16_t*)xproj, (const bf16_t*)wfrag, (const int*)lens,
-                     (const long long*)row_off, (const int*)tcap, (const int*)perm, (bf16_t*)y, N, T, ndir);
+                     (const long long*)row_off, (const int*)tcap, (const int*)perm, (bf16_t*)y, N, T, ndir, (bf16_t*)nullptr,
+                     (float*)nullptr);
   return DLAMD_CHECK_LAUNCH();
 }
 

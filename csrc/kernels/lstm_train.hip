@@ -18,6 +18,8 @@
 // One workgroup = 16 sequences of one direction, 4 waves; no grid-level synchronisation.
 // Packed-sequence semantics (nn.utils.rnn.pack_padded_sequence): the reverse direction starts at len-1,
 // steps at t >= len produce zeros and receive no gradient.
+#include <stdlib.h>
+
 #include "common.h"
 
 __device__ __forceinline__ float lt_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
@@ -176,27 +178,45 @@ __global__ __launch_bounds__(256) void lstm_train_bwd_kernel(const float* __rest
 #pragma unroll
   for (int i = 0; i < MT * 4; ++i) dcr[i] = 0.f;
 
-  for (int step = maxlen - 1; step >= 0; --step) {
-    const bool act = step < len;
+  // inputs of a step (dY, c_t, c_{t-1}, the four gates of every unit this lane owns): fetched one step ahead, under the
+  // previous step's MFMAs - at the top of the step their latency (~2 us) was exposed in every one of the T steps
+  f32x4 pdy[MT], pcv[MT], pcp[MT];
+  u32x2 pg[MT][4];
+  auto fetch = [&](int step) {
+    const bool act = step >= 0 && step < len;
     const int t = dir == 0 ? step : (len - 1 - step);
     const int tp = dir == 0 ? t - 1 : t + 1;
-    const bool has_prev = step > 0;
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
       const int A = wave * MT + a;
-      f32x4 dyv = {0.f, 0.f, 0.f, 0.f}, cv = dyv, cpv = dyv;
-      u32x2 graw[4] = {};
-      if (act) {
-        dyv = *reinterpret_cast<const f32x4*>(dyp + (long long)t * yrow + A * 16);
-        cv = *reinterpret_cast<const f32x4*>(cp + (long long)t * yrow + A * 16);
-        if (has_prev) cpv = *reinterpret_cast<const f32x4*>(cp + (long long)tp * yrow + A * 16);
+      pdy[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+      pcv[a] = pdy[a];
+      pcp[a] = pdy[a];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) graw[j] = *reinterpret_cast<const u32x2*>(gp + (long long)t * xrow + (A * 4 + j) * 16);
+      for (int j = 0; j < 4; ++j) pg[a][j] = u32x2{0u, 0u};
+      if (act) {
+        pdy[a] = *reinterpret_cast<const f32x4*>(dyp + (long long)t * yrow + A * 16);
+        pcv[a] = *reinterpret_cast<const f32x4*>(cp + (long long)t * yrow + A * 16);
+        if (step > 0) pcp[a] = *reinterpret_cast<const f32x4*>(cp + (long long)tp * yrow + A * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pg[a][j] = *reinterpret_cast<const u32x2*>(gp + (long long)t * xrow + (A * 4 + j) * 16);
       }
+    }
+  };
+  fetch(maxlen - 1);
+
+  for (int step = maxlen - 1; step >= 0; --step) {
+    const bool act = step < len;
+    const int t = dir == 0 ? step : (len - 1 - step);
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+      const int A = wave * MT + a;
+      const f32x4 dyv = pdy[a], cv = pcv[a], cpv = pcp[a];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float ig = bf16_bits_to_f32(graw[j][0] & 0xffffu), fg = bf16_bits_to_f32(graw[j][0] >> 16);
-        const float gg = bf16_bits_to_f32(graw[j][1] & 0xffffu), og = bf16_bits_to_f32(graw[j][1] >> 16);
+        const u32x2 graw = pg[a][j];
+        const float ig = bf16_bits_to_f32(graw[0] & 0xffffu), fg = bf16_bits_to_f32(graw[0] >> 16);
+        const float gg = bf16_bits_to_f32(graw[1] & 0xffffu), og = bf16_bits_to_f32(graw[1] >> 16);
         const float dht = dyv[j] + dh[a][j];
         const float tc = lt_tanh(cv[j]);
         const float dc = dcr[a * 4 + j] + dht * og * (1.f - tc * tc);
@@ -215,6 +235,7 @@ __global__ __launch_bounds__(256) void lstm_train_bwd_kernel(const float* __rest
     }
     __syncthreads();
     if (step == 0) break;   // dh of the first processed step has no consumer
+    fetch(step - 1);        // in flight under the MFMAs below
     const bf16_t* wts = wt;
     asm volatile("" : "+v"(wts));
 #pragma unroll
@@ -251,13 +272,24 @@ static int lt_launch_bwd(const void* dy, const void* gact, const void* cbuf, con
 }
 
 // Shapes are the caller's contract (ops/lstm_train.py checks tensor sizes against N, T, H, ndir).
+// lstm.hip: the inference kernel with three quarters of W_hh resident (registers + LDS), saving gates and cell states
+int dlamd_lstm4_train_fwd(const void* xproj, const void* wfrag, const void* lens, void* y, void* gact, void* cbuf, int N, int T,
+                          int ndir, hipStream_t stream);
+
 extern "C" int dlamd_lstm_train_fwd(const void* xproj, const void* wfrag, const void* lens, void* y, void* gact, void* cbuf, int N,
                                     int T, int H, int ndir, hipStream_t st) {
   if (!xproj || !wfrag || !y || !gact || !cbuf || N <= 0 || T <= 0 || ndir < 1 || ndir > 2) return -1;
   switch (H) {
     case 64: return lt_launch_fwd<64>(xproj, wfrag, lens, y, gact, cbuf, N, T, ndir, st);
     case 128: return lt_launch_fwd<128>(xproj, wfrag, lens, y, gact, cbuf, N, T, ndir, st);
-    case 256: return lt_launch_fwd<256>(xproj, wfrag, lens, y, gact, cbuf, N, T, ndir, st);
+    case 256: {
+      // H = 256: the kernel that keeps three quarters of W_hh in registers + LDS (4.0 us per step against 7.0 with the
+      // whole matrix streamed from L2 every step: one CU pulls ~100 GB/s); DLAMD_LSTM_TRAIN_STREAMED=1 keeps the
+      // streaming kernel
+      static const bool streamed = getenv("DLAMD_LSTM_TRAIN_STREAMED") != nullptr && atoi(getenv("DLAMD_LSTM_TRAIN_STREAMED")) != 0;
+      if (!streamed) return dlamd_lstm4_train_fwd(xproj, wfrag, lens, y, gact, cbuf, N, T, ndir, st);
+      return lt_launch_fwd<256>(xproj, wfrag, lens, y, gact, cbuf, N, T, ndir, st);
+    }
     default: return -2;
   }
 }
