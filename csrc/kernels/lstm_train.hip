@@ -253,6 +253,194 @@ __global__ __launch_bounds__(256) void lstm_train_bwd_kernel(const float* __rest
   }
 }
 
+// Backward recurrence for H = 256 with most of W_hh^T resident: 8 waves, each owns 2 of the 16 hidden-unit tiles
+// (64 fragments of 1 KB): K-steps 0 .. KR-1 live in registers, the next KL in LDS, the last NS = 32 - KR - KL are
+// streamed from L2 in two batches through one small register buffer (the first batch is fetched during the previous
+// step, the second while the resident K-steps are multiplied).  The streaming kernel above pulls all 512 KB per step
+// through one CU's L2 port (~100 GB/s): 9 us per step.
+template <int KR, int KL>
+__global__ __launch_bounds__(512) void lstm_train_bwd_res_kernel(const float* __restrict__ dy, const bf16_t* __restrict__ gact,
+                                                                 const float* __restrict__ cbuf, const bf16_t* __restrict__ wtfrag,
+                                                                 const int* __restrict__ lens, bf16_t* __restrict__ dg, int N,
+                                                                 int T, int ndir) {
+  constexpr int H = 256, G = 4 * H, NW = 8;
+  constexpr int MT = H / 16 / NW;    // 2 output tiles per wave
+  constexpr int KS = G / 32;         // 32 k-steps over the gate columns
+  constexpr int GROW = G * 2 + 16;
+  constexpr int S0 = KR + KL;        // first streamed k-step
+  constexpr int NS = KS - S0;
+  constexpr int B1 = (NS + 1) / 2, B2 = NS - B1;   // k-steps of the two streamed batches
+  static_assert(NS >= 2 && B1 >= B2, "streamed k-steps");
+  extern __shared__ __attribute__((aligned(16))) char lt_smem[];
+  char* gbuf = lt_smem;                         // [16][GROW]
+  char* wl = lt_smem + 16 * GROW;               // [wave][KL][MT][64 lanes] x 16 B
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int seq_l = lane & 15, fq = lane >> 4;
+  const int dir = blockIdx.y;
+  const int n = blockIdx.x * 16 + seq_l;
+  const bool seq_ok = n < N;
+  const int len = seq_ok ? (lens ? min(max(lens[n], 0), T) : T) : 0;
+  int maxlen = len;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
+
+  const bf16_t* wt = wtfrag + (long long)dir * G * H + (long long)wave * MT * KS * 64 * 8 + lane * 8;
+  const long long xrow = (long long)ndir * G, yrow = (long long)ndir * H;
+  const long long row0 = (long long)(seq_ok ? n : 0) * T;
+  const bf16_t* gp = gact + row0 * xrow + (long long)dir * G + fq * 4;
+  bf16_t* dgp = dg + row0 * xrow + (long long)dir * G + fq * 4;
+  const float* cp = cbuf + row0 * yrow + (long long)dir * H + fq * 4;
+  const float* dyp = dy + row0 * yrow + (long long)dir * H + fq * 4;
+
+  bf16x8 wr[KR][MT];
+#pragma unroll
+  for (int k = 0; k < KR; ++k)
+#pragma unroll
+    for (int a = 0; a < MT; ++a) wr[k][a] = *reinterpret_cast<const bf16x8*>(wt + (long long)(a * KS + k) * 64 * 8);
+  char* wlw = wl + ((wave * KL * MT) * 64 + lane) * 16;
+#pragma unroll
+  for (int k = 0; k < KL; ++k)
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+      *reinterpret_cast<bf16x8*>(wlw + (k * MT + a) * 1024) =
+          *reinterpret_cast<const bf16x8*>(wt + (long long)(a * KS + KR + k) * 64 * 8);
+
+  f32x4 dh[MT];
+  float dcr[MT * 4];
+#pragma unroll
+  for (int a = 0; a < MT; ++a) dh[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < MT * 4; ++i) dcr[i] = 0.f;
+
+  f32x4 pdy[MT], pcv[MT], pcp[MT];
+  u32x2 pg[MT][4];
+  auto fetch = [&](int step) {
+    const bool act = step >= 0 && step < len;
+    const int t = dir == 0 ? step : (len - 1 - step);
+    const int tp = dir == 0 ? t - 1 : t + 1;
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+      const int A = wave * MT + a;
+      pdy[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+      pcv[a] = pdy[a];
+      pcp[a] = pdy[a];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pg[a][j] = u32x2{0u, 0u};
+      if (act) {
+        pdy[a] = *reinterpret_cast<const f32x4*>(dyp + (long long)t * yrow + A * 16);
+        pcv[a] = *reinterpret_cast<const f32x4*>(cp + (long long)t * yrow + A * 16);
+        if (step > 0) pcp[a] = *reinterpret_cast<const f32x4*>(cp + (long long)tp * yrow + A * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pg[a][j] = *reinterpret_cast<const u32x2*>(gp + (long long)t * xrow + (A * 4 + j) * 16);
+      }
+    }
+  };
+  fetch(maxlen - 1);
+  bf16x8 ws[B1][MT];     // streamed fragments: batch 1 (k-steps S0 .. S0+B1-1), then batch 2 in the same registers
+#pragma unroll
+  for (int k = 0; k < B1; ++k)
+#pragma unroll
+    for (int a = 0; a < MT; ++a) ws[k][a] = *reinterpret_cast<const bf16x8*>(wt + (long long)(a * KS + S0 + k) * 64 * 8);
+  __syncthreads();       // LDS-resident weights are in place
+
+  for (int step = maxlen - 1; step >= 0; --step) {
+    const bool act = step < len;
+    const int t = dir == 0 ? step : (len - 1 - step);
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+      const int A = wave * MT + a;
+      const f32x4 dyv = pdy[a], cv = pcv[a], cpv = pcp[a];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32x2 graw = pg[a][j];
+        const float ig = bf16_bits_to_f32(graw[0] & 0xffffu), fg = bf16_bits_to_f32(graw[0] >> 16);
+        const float gg = bf16_bits_to_f32(graw[1] & 0xffffu), og = bf16_bits_to_f32(graw[1] >> 16);
+        const float dht = dyv[j] + dh[a][j];
+        const float tc = lt_tanh(cv[j]);
+        const float dc = dcr[a * 4 + j] + dht * og * (1.f - tc * tc);
+        const float d_o = dht * tc * og * (1.f - og);
+        const float d_i = dc * gg * ig * (1.f - ig);
+        const float d_g = dc * ig * (1.f - gg * gg);
+        const float d_f = dc * cpv[j] * fg * (1.f - fg);
+        u32x2 out = {0u, 0u};
+        if (act) {
+          dcr[a * 4 + j] = dc * fg;
+          out = u32x2{lt_pack2(d_i, d_f), lt_pack2(d_g, d_o)};
+          *reinterpret_cast<u32x2*>(dgp + (long long)t * xrow + (A * 4 + j) * 16) = out;
+        }
+        *reinterpret_cast<u32x2*>(&gbuf[seq_l * GROW + ((A * 4 + j) * 16 + fq * 4) * 2]) = out;
+      }
+    }
+    __syncthreads();
+    if (step == 0) break;
+    fetch(step - 1);
+    const bf16_t* wts = wt;
+    asm volatile("" : "+v"(wts));          // keep the streamed loads inside the step loop
+    const char* gb = gbuf + seq_l * GROW + fq * 16;
+#pragma unroll
+    for (int a = 0; a < MT; ++a) dh[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // streamed batch 1 (arrived during the previous step), then batch 2 is requested into the same registers
+#pragma unroll
+    for (int k = 0; k < B1; ++k) {
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(gb + (S0 + k) * 64);
+#pragma unroll
+      for (int a = 0; a < MT; ++a) dh[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws[k][a], b, dh[a], 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < B2; ++k)
+#pragma unroll
+      for (int a = 0; a < MT; ++a) ws[k][a] = *reinterpret_cast<const bf16x8*>(wts + (long long)(a * KS + S0 + B1 + k) * 64 * 8);
+    // resident: registers
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(gb + k * 64);
+#pragma unroll
+      for (int a = 0; a < MT; ++a) dh[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[k][a], b, dh[a], 0, 0, 0);
+    }
+    // resident: LDS
+#pragma unroll
+    for (int k = 0; k < KL; ++k) {
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(gb + (KR + k) * 64);
+#pragma unroll
+      for (int a = 0; a < MT; ++a) {
+        const bf16x8 w = *reinterpret_cast<const bf16x8*>(wlw + (k * MT + a) * 1024);
+        dh[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, b, dh[a], 0, 0, 0);
+      }
+    }
+    // streamed batch 2
+#pragma unroll
+    for (int k = 0; k < B2; ++k) {
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(gb + (S0 + B1 + k) * 64);
+#pragma unroll
+      for (int a = 0; a < MT; ++a) dh[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws[k][a], b, dh[a], 0, 0, 0);
+    }
+    // batch 1 of the next step
+#pragma unroll
+    for (int k = 0; k < B1; ++k)
+#pragma unroll
+      for (int a = 0; a < MT; ++a) ws[k][a] = *reinterpret_cast<const bf16x8*>(wts + (long long)(a * KS + S0 + k) * 64 * 8);
+    __syncthreads();   // every wave has read this step's dG tile before the next step overwrites it
+  }
+}
+
+static int lt_launch_bwd_res(const void* dy, const void* gact, const void* cbuf, const void* wtfrag, const void* lens, void* dg, int N,
+                             int T, int ndir, hipStream_t st) {
+  constexpr int KR = 16, KL = 7;
+  const size_t smem = 16 * (4 * 256 * 2 + 16) + (size_t)8 * KL * 2 * 1024;
+  auto k = lstm_train_bwd_res_kernel<KR, KL>;
+  static bool set = false;
+  if (!set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return -5;
+    set = true;
+  }
+  dim3 grid((N + 15) / 16, ndir);
+  hipLaunchKernelGGL(k, grid, dim3(512), smem, st, (const float*)dy, (const bf16_t*)gact, (const float*)cbuf, (const bf16_t*)wtfrag,
+                     (const int*)lens, (bf16_t*)dg, N, T, ndir);
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
+
 template <int H>
 static int lt_launch_fwd(const void* xproj, const void* wfrag, const void* lens, void* y, void* gact, void* cbuf, int N, int T,
                          int ndir, hipStream_t st) {
@@ -300,7 +488,11 @@ extern "C" int dlamd_lstm_train_bwd(const void* dy, const void* gact, const void
   switch (H) {
     case 64: return lt_launch_bwd<64>(dy, gact, cbuf, wtfrag, lens, dg, N, T, ndir, st);
     case 128: return lt_launch_bwd<128>(dy, gact, cbuf, wtfrag, lens, dg, N, T, ndir, st);
-    case 256: return lt_launch_bwd<256>(dy, gact, cbuf, wtfrag, lens, dg, N, T, ndir, st);
+    case 256: {
+      static const bool streamed = getenv("DLAMD_LSTM_TRAIN_STREAMED") != nullptr && atoi(getenv("DLAMD_LSTM_TRAIN_STREAMED")) != 0;
+      if (!streamed) return lt_launch_bwd_res(dy, gact, cbuf, wtfrag, lens, dg, N, T, ndir, st);
+      return lt_launch_bwd<256>(dy, gact, cbuf, wtfrag, lens, dg, N, T, ndir, st);
+    }
     default: return -2;
   }
 }
