@@ -111,7 +111,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     if (un < p.units) fetch(un);   // in flight under the MFMAs below
 #pragma unroll
     for (int ks = 0; ks < WG_PX / 32; ++ks) {
-      bf16x8 a[4];
+      // all fragments of the K-step first (13 transposed reads in flight together), then its 36 MFMAs: with one wave
+      // per SIMD nothing else hides an LDS round trip per tap
+      bf16x8 a[4], b[9];
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[i] = tr_frag(dys, 32 * ks, 1, i * 16, lane);
 #pragma unroll
@@ -119,10 +121,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
         // every lane executes the transposed read (it needs the whole wave); taps beyond kh * kw read tap 0 and are dropped
         const int tt = t < taps ? t : 0;
         const int r = tt / p.kw, s = tt - r * p.kw;
-        const bf16x8 b = tr_frag(xs, r * PW + s + 32 * ks * p.sw, p.sw, wave * 16, lane);
+        b[t] = tr_frag(xs, r * PW + s + 32 * ks * p.sw, p.sw, wave * 16, lane);
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
         if (t < taps) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][t], 0, 0, 0);
+          for (int i = 0; i < 4; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
         }
       }
     }
