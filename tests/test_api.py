@@ -177,6 +177,11 @@ def test_result_survives_expired_status_key(ctx):
     with TestClient(app) as c:
         _post(c, b"%PDF-1.4", "old")
         assert _wait(c, "old") == "completed"
+        # "completed" is written twice (preview, then the full text): wait for the second write, or it lands after
+        # the delete below and revives the key
+        t_end = time.time() + 30
+        while "result_preview" in (status.get("old") or {}) and time.time() < t_end:
+            time.sleep(0.01)
         status.delete("old")                                      # TTL lapsed; the Mongo row never expires
         assert c.get("/check-status/old").status_code == 404
         r = c.get("/result/old")
