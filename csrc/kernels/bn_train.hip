@@ -59,16 +59,21 @@ __device__ __forceinline__ void bn_block_reduce(const float (&a)[8], const float
 
 // sums[i] = sum over workgroups of partial[g][i], i < 2 C (atomics on 2 C addresses from thousands of workgroups
 // serialise in one cache line; a second pass over a few hundred partial rows costs microseconds)
-__global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict__ partial, float* __restrict__ sums, int G, int n) {
-  __shared__ float lds[256];
-  const int il = threadIdx.x & 63, part = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + il;
+__global__ __launch_bounds__(1024) void bn_finish_kernel(const float* __restrict__ partial, float* __restrict__ sums, int G, int n) {
+  // 16 output sums per workgroup, 64 threads per sum: each adds every 64th partial row, then a wave-wide tree
+  __shared__ float lds[1024];
+  const int il = threadIdx.x & 15, part = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + il;
   float s = 0.f;
   if (i < n)
-    for (int g = part; g < G; g += 4) s += partial[(long long)g * n + i];
+    for (int g = part; g < G; g += 64) s += partial[(long long)g * n + i];
   lds[threadIdx.x] = s;
   __syncthreads();
-  if (part == 0 && i < n) sums[i] = lds[il] + lds[64 + il] + lds[128 + il] + lds[192 + il];
+  for (int h = 32; h > 0; h >>= 1) {
+    if (part < h) lds[threadIdx.x] += lds[threadIdx.x + h * 16];
+    __syncthreads();
+  }
+  if (part == 0 && i < n) sums[i] = lds[il];
 }
 
 // partial[g][0][C] = sum z, partial[g][1][C] = sum z^2 over the slabs of workgroup g
@@ -245,7 +250,7 @@ extern "C" int dlamd_bn_train_fwd(const void* z, const float* gamma, const float
   const long long chunks = P * (C / 8);
   if ((chunks + 255) / 256 > 0x7fffffffLL) return -3;
   hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, (const bf16_t*)z, partial, P, C);
-  hipLaunchKernelGGL(bn_finish_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, stream, (const float*)partial, sums, (int)wgs, 2 * C);
+  hipLaunchKernelGGL(bn_finish_kernel, dim3((2 * C + 15) / 16), dim3(1024), 0, stream, (const float*)partial, sums, (int)wgs, 2 * C);
   long long awgs = (P + BN_ROWS_PER_WG - 1) / BN_ROWS_PER_WG;
   if (awgs > 4096) awgs = 4096;
   hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)awgs), dim3(256), 0, stream, (const bf16_t*)z, sums, gamma,
@@ -265,7 +270,7 @@ extern "C" int dlamd_bn_train_bwd(const void* dy, const void* z, const float* me
   if ((chunks + 255) / 256 > 0x7fffffffLL) return -3;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)z, mean,
                      invstd, gamma, beta, partial, P, C, act);
-  hipLaunchKernelGGL(bn_finish_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, stream, (const float*)partial, sums, (int)wgs, 2 * C);
+  hipLaunchKernelGGL(bn_finish_kernel, dim3((2 * C + 15) / 16), dim3(1024), 0, stream, (const float*)partial, sums, (int)wgs, 2 * C);
   long long awgs = (P + BN_ROWS_PER_WG - 1) / BN_ROWS_PER_WG;
   if (awgs > 4096) awgs = 4096;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)awgs), dim3(256), 0, stream, (const bf16_t*)dy,

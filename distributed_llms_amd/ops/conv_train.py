@@ -23,6 +23,24 @@ from . import _loader
 from . import conv as C
 
 
+def _stride2_tap_table() -> torch.Tensor:
+    """Source tap (r * 3 + s, 9 = none) of the 2 x 2 gradient filter entry (parity group g = py * 2 + px, da, db)."""
+    idx = []
+    for py in range(2):
+        for px in range(2):
+            for da in range(2):
+                for db in range(2):
+                    r, sx = py - 2 * da + 1, px - 2 * db + 1
+                    idx.append(r * 3 + sx if 0 <= r < 3 and 0 <= sx < 3 else 9)
+    return torch.tensor(idx, dtype=torch.long)
+
+
+_S2_TAPS = _stride2_tap_table()
+# vertical stride 2, horizontal stride 1: (row parity py, da, column tap s of the column-flipped filter) -> r * 3 + s
+_S21_TAPS = torch.tensor([(py - 2 * da + 1) * 3 + sx if 0 <= py - 2 * da + 1 < 3 else 9
+                          for py in range(2) for da in range(2) for sx in range(3)], dtype=torch.long)
+
+
 def wgrad_serves(cin: int, cout: int, kh: int, kw: int, sh: int, sw: int) -> bool:
     return cin % 64 == 0 and cout % 64 == 0 and 1 <= kh <= 3 and 1 <= kw <= 3 and 1 <= sw <= 2 and 1 <= sh <= 4
 
@@ -57,6 +75,28 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, in_hw: Tuple[int, int], stride
     wt = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()
     if sh == 1 and sw == 1 and kh - 1 - ph >= 0 and kw - 1 - pw >= 0 and H == Ho + kh - 1 - 2 * ph and W == Wo + kw - 1 - 2 * pw:
         return C.conv2d_nhwc(dy, wt, None, stride=1, padding=(kh - 1 - ph, kw - 1 - pw))
+    if (sh, sw) == (2, 2) and (kh, kw) == (3, 3) and (ph, pw) == (1, 1) and Cin % 4 == 0:
+        # stride 2: the four parities of the input position each see a 2 x 2 window of the output gradient (rows a, a + 1
+        # and columns b, b + 1 for input pixel (2 a + py, 2 b + px); tap r = py - 2 da + 1, s = px - 2 db + 1).  Stacked
+        # as four channel groups they are ONE 2 x 2 convolution whose pixel-shuffle store writes dX in place: 16 tap
+        # blocks (9 of them non-zero) instead of the 36 of the zero-spread form, and no spread buffer.
+        w9 = torch.cat([w.reshape(Cout, 9, Cin), w.new_zeros((Cout, 1, Cin))], dim=1)        # tap 9 = the zero tap
+        w4 = w9[:, _S2_TAPS.to(w.device)].reshape(Cout, 4, 2, 2, Cin).permute(1, 4, 2, 3, 0).reshape(4 * Cin, 2, 2, Cout)
+        w4 = w4.contiguous()
+        dyp = F.pad(dy, (0, 0, 0, 1, 0, 1))
+        dx = C.conv2d_nhwc(dyp, w4, None, stride=1, padding=0, out_mode=C.OUT_PIXEL_SHUFFLE)
+        if dx.shape[1] != H or dx.shape[2] != W:
+            dx = dx[:, :H, :W].contiguous()
+        return dx
+    if (sh, sw) == (2, 1) and (kh, kw) == (3, 3) and (ph, pw) == (1, 1) and H == 2 * Ho:
+        # vertical stride 2: the two row parities as two channel groups of one 2 x 3 convolution (rows a, a + 1 of the
+        # gradient for input row 2 a + py: tap r = py - 2 da + 1; the three column taps turned round as for stride 1),
+        # then one copy that interleaves the rows - 12 tap blocks instead of 18, no spread buffer
+        w9 = torch.cat([w.flip(2).reshape(Cout, 9, Cin), w.new_zeros((Cout, 1, Cin))], dim=1)
+        w2 = w9[:, _S21_TAPS.to(w.device)].reshape(Cout, 2, 2, 3, Cin).permute(1, 4, 2, 3, 0).reshape(2 * Cin, 2, 3, Cout)
+        dyp = F.pad(dy, (0, 0, 0, 0, 0, 1))
+        out = C.conv2d_nhwc(dyp, w2.contiguous(), None, stride=1, padding=(0, 1))            # [N, Ho, W, 2 Cin]
+        return out.view(N, Ho, W, 2, Cin).permute(0, 1, 3, 2, 4).reshape(N, H, W, Cin)
     # general case: gradient samples placed on the padded input grid, then a VALID stride-1 convolution
     buf = torch.zeros((N, H + kh - 1, W + kw - 1, Cout), dtype=dy.dtype, device=dy.device)
     oy0, ox0 = kh - 1 - ph, kw - 1 - pw
