@@ -116,6 +116,8 @@ class EngineService:
 
     def _load_and_push(self, job: _Job, doc: reader.PdfDocument, i: int, prior) -> None:
         if job.failed:
+            with self._mu:
+                self._outstanding -= 1
             return
         self._slots.acquire()
         pushed = False
