@@ -79,6 +79,7 @@ def test_a_broken_document_fails_alone(extractor):
     for t in th:
         t.join(120)
     assert res["bad"]["status"] == "failed" and res["good"]["status"] == "completed" and res["good"]["pages"] == 2
+    assert extractor.service._outstanding == 0        # nothing is still counted as on its way to the engine
 
 
 def test_process_pdfs_reports_errors_per_document():
