@@ -408,6 +408,21 @@ class OcrEngine:
                     rows = np.zeros((q.shape[0], 8), np.float32)
                     rows[:, :5] = q[:, :5]
                     rows[:, 7] = 1.0
+                    # on a skewed scan the formula map gives the upright bounding box of a slanted formula: take the
+                    # page's skew from its text lines, solve the box for the turned rectangle (as the text boxes are)
+                    # and let the crop kernel turn it upright - the formula recogniser is trained on level formulas
+                    th = float(np.median(r[:, 6])) if r.shape[0] >= 3 else 0.0
+                    if 0.004 <= abs(th) <= 0.35:
+                        c, sn = np.cos(th), abs(np.sin(th))
+                        c2 = c * c - sn * sn
+                        Wb, Hb = rows[:, 2] - rows[:, 0], rows[:, 3] - rows[:, 1]
+                        L, T = (Wb * c - Hb * sn) / c2, (Hb * c - Wb * sn) / c2
+                        okr = (L >= 0.5 * Wb) & (T >= 0.35 * Hb) & (T >= cfg.formula_min_side_px * 0.5)
+                        cxr, cyr = 0.5 * (rows[:, 0] + rows[:, 2]), 0.5 * (rows[:, 1] + rows[:, 3])
+                        L, T = np.where(okr, L, Wb), np.where(okr, T, Hb)
+                        rows[:, 0], rows[:, 2] = cxr - 0.5 * L, cxr + 0.5 * L
+                        rows[:, 1], rows[:, 3] = cyr - 0.5 * T, cyr + 0.5 * T
+                        rows[:, 6] = np.where(okr, th, 0.0)
                     r = np.concatenate([r[~inside], rows], 0)
             fg = np.zeros((0, 4), np.float32)
             if figs is not None and figs[pi].shape[0]:
@@ -639,8 +654,8 @@ class OcrEngine:
                 self._formula_event = torch.cuda.Event()
                 self._formula_event.record(db.stream)
                 return idx, h_tok, h_cf, (host, dev, x)
-            regions = [rs.Region(db.srcs[page_of[i]], tuple(float(v) for v in boxes[i, :4]), int(oh[k]), int(ow[k]))
-                       for k, i in enumerate(idx)]
+            regions = [rs.Region(db.srcs[page_of[i]], tuple(float(v) for v in boxes[i, :4]), int(oh[k]), int(ow[k]), 0,
+                                 float(boxes[i, 4]) if boxes.shape[1] > 4 else 0.0) for k, i in enumerate(idx)]
             x = rs.resample_regions(regions, H, W, rs.HALF_MEAN, rs.HALF_STD)
             toks, conf = self.formula_rec.generate(x, max_len=cfg.formula_max_tokens, use_graph=False, eos_check_every=8)
             return idx, toks.to(torch.int32), conf.float(), None
