@@ -188,13 +188,13 @@ def create_app(settings: Optional[Settings] = None, status: Optional[StatusStore
             clen = request.headers.get("content-length")
             try:
                 # the body is consumed as it arrives: the cap holds for chunked uploads too, and the file's SHA-256
-                # is computed on an I/O thread while the rest of the upload is still on the wire
+                # is computed on a helper thread while the rest of the upload is still on the wire
                 form = StreamingForm(request.headers.get("content-type"), MAX_UPLOAD_BYTES,
                                      int(clen) if clen and clen.isdigit() else None,
-                                     hash_pool=request.app.state.ctx["jobs"].io_pool)
+                                     hash_pool=request.app.state.ctx["jobs"].hash_pool)
                 async for chunk in request.stream():
                     form.feed(chunk)
-                parts = form.finish()
+                parts = form.finish(defer_hash=True)
             except UploadTooLarge:
                 _count("extract", 413)
                 return JSONResponse({"detail": "upload too large"}, status_code=413)
@@ -218,13 +218,21 @@ def create_app(settings: Optional[Settings] = None, status: Optional[StatusStore
                 _count("extract", 400)
                 return JSONResponse({"detail": "document_id is required"}, status_code=400)
             file_bytes = file_part.data                 # a view of the receive buffer: the PDF is never copied again
-            document_hash = form.sha256_hex() or hashlib.sha256(file_bytes).hexdigest()
+            # the hash thread may still be a few pieces behind the wire: the job starts without waiting for it, and
+            # the digest joins the status record with the job's first write (the 'queued' record carries it only
+            # when it is ready by now)
+            hash_fut = form.sha256_pending()
+            if hash_fut is not None and not hash_fut.done():
+                document_hash = None
+            else:
+                hash_fut = None
+                document_hash = form.sha256_hex() or hashlib.sha256(file_bytes).hexdigest()
             jobs: JobManager = request.app.state.ctx["jobs"]
             existing = await jobs.claim(document_id, document_hash, file_part.filename or "")
             if existing is not None:
                 _count("extract", 200)
                 return {"status": existing.get("status", "unknown")}
-            jobs.start(file_bytes, document_id, document_hash)
+            jobs.start(file_bytes, document_id, document_hash, hash_future=hash_fut)
             _count("extract", 200)
             return {"status": "ok"}
         except Exception as e:  # noqa: BLE001

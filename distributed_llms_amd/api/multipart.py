@@ -13,7 +13,9 @@ dependency here.  Two entry points:
 """
 from __future__ import annotations
 
+import collections
 import re
+import threading
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 from urllib.parse import unquote
@@ -154,7 +156,10 @@ class StreamingForm:
         self.hash_pool = hash_pool
         self.max_parts = max_parts
         self._sha = hashlib.sha256()
-        self._hash_futs = []
+        self._hash_futs = []             # one future per drain task; all done <=> every submitted piece is hashed
+        self._hash_queue = collections.deque()
+        self._hash_lock = threading.Lock()
+        self._hash_running = False
         # incremental scan state (only with a preallocated buffer; otherwise everything happens in finish())
         self._pos = -1                   # -1: opening delimiter not seen yet
         self._in_file = False
@@ -225,18 +230,28 @@ class StreamingForm:
         view = memoryview(self.buf)[lo:hi]       # the buffer is preallocated and never resized: the view stays valid
         if self.hash_pool is None:
             self._sha.update(view)
-        else:
-            # one piece at a time and in order: each task waits for its predecessor
-            prev = self._hash_futs[-1] if self._hash_futs else None
+            return
+        # pieces are hashed in order by at most ONE pool task per form: a piece either joins the running task's queue
+        # or starts a new task (no pool worker ever blocks waiting for a predecessor)
+        with self._hash_lock:
+            self._hash_queue.append(view)
+            if not self._hash_running:
+                self._hash_running = True
+                self._hash_futs.append(self.hash_pool.submit(self._hash_drain))
 
-            def run(v=view, prev=prev):
-                if prev is not None:
-                    prev.result()
-                self._sha.update(v)
+    def _hash_drain(self) -> None:
+        while True:
+            with self._hash_lock:
+                if not self._hash_queue:
+                    self._hash_running = False
+                    return
+                view = self._hash_queue.popleft()
+            self._sha.update(view)
 
-            self._hash_futs.append(self.hash_pool.submit(run))
-
-    def finish(self) -> List[Part]:
+    def finish(self, defer_hash: bool = False) -> List[Part]:
+        """Parse the complete body.  With ``defer_hash`` the call does not wait for the hash thread to catch up with
+        the last pieces (10-30 ms behind the wire on a 120 MB upload): ``sha256_pending()`` then returns a future of
+        the digest, and the caller can start work on the file meanwhile."""
         import hashlib
 
         if self.fixed:
@@ -250,19 +265,37 @@ class StreamingForm:
         # those bytes again (a second pass over a 120 MB upload is 30-50 ms on the event loop, after the last byte)
         parts = _parse_view(body, self.delim, self.max_parts, self._file_span if self.fixed else None)
         self._digest = None
-        if self._file_span is not None:
-            for f in self._hash_futs:
-                f.result()
-            tgt = next((p for p in parts if p.name == self.hash_field and p.is_file), None)
-            if tgt is not None and len(tgt.data) == self._file_span[1] - self._file_span[0] and self._hashed_to == self._file_span[1]:
-                self._digest = self._sha.hexdigest()
-        if self._digest is None:
-            tgt = next((p for p in parts if p.name == self.hash_field and p.is_file), None)
-            if tgt is not None:
-                self._digest = hashlib.sha256(tgt.data).hexdigest()
+        self._digest_fut = None
+        tgt = next((p for p in parts if p.name == self.hash_field and p.is_file), None)
+        streamed = (self._file_span is not None and tgt is not None
+                    and len(tgt.data) == self._file_span[1] - self._file_span[0]
+                    and self._hashed_to == self._file_span[1])
+        if streamed and defer_hash and self.hash_pool is not None and self._hash_futs:
+            futs = list(self._hash_futs)
+
+            def digest():
+                for f in futs:
+                    f.result()
+                return self._sha.hexdigest()
+
+            self._digest_fut = self.hash_pool.submit(digest)
+            return parts
+        for f in self._hash_futs:
+            f.result()
+        if streamed:
+            self._digest = self._sha.hexdigest()
+        elif tgt is not None:
+            self._digest = hashlib.sha256(tgt.data).hexdigest()
         return parts
 
+    def sha256_pending(self):
+        """The digest's future after ``finish(defer_hash=True)`` left the hash thread running, else None."""
+        return getattr(self, "_digest_fut", None)
+
     def sha256_hex(self) -> Optional[str]:
+        fut = getattr(self, "_digest_fut", None)
+        if fut is not None:
+            return fut.result()
         return getattr(self, "_digest", None)
 
 

@@ -17,6 +17,7 @@ What is new relative to the reference:
 from __future__ import annotations
 
 import asyncio
+import hashlib
 import datetime
 import logging
 import time
@@ -43,6 +44,9 @@ class JobManager:
         self.node_id = node_id
         self.deadline_s = deadline_s
         self.io_pool = ThreadPoolExecutor(max_workers=io_threads, thread_name_prefix="dlamd-io")
+        # upload digests run beside the receive loop; a pool of their own keeps a status write from queueing behind
+        # a hundred megabytes of hashing
+        self.hash_pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="dlamd-hash")
         # extraction calls block on the GPU workers; they get their own pool so I/O never queues behind them, and
         # enough threads that every concurrent upload has its pages in the batcher at the same time (with 8, a burst
         # of 32 four-page scans reached the engine as 8-page batches)
@@ -69,22 +73,31 @@ class JobManager:
         await self._io(self.status.update, document_id, data)
         return None
 
-    def start(self, pdf_bytes: bytes, document_id: str, document_hash: Optional[str]) -> asyncio.Task:
-        """Fire-and-forget background job (ocr_service.py:460); the task is kept referenced until done."""
-        t = asyncio.create_task(self.process(pdf_bytes, document_id, document_hash))
+    def start(self, pdf_bytes: bytes, document_id: str, document_hash: Optional[str], hash_future=None) -> asyncio.Task:
+        """Fire-and-forget background job (ocr_service.py:460); the task is kept referenced until done.
+        ``hash_future``: a ``concurrent.futures.Future`` of the digest when it is still being computed."""
+        t = asyncio.create_task(self.process(pdf_bytes, document_id, document_hash, hash_future))
         self.tasks.add(t)
         t.add_done_callback(self.tasks.discard)
         metrics.JOBS_IN_FLIGHT.set(len(self.tasks))
         return t
 
     # ------------------------------------------------------------------ the job
-    async def process(self, pdf_bytes: bytes, document_id: str, document_hash: Optional[str] = None) -> Dict[str, str]:
+    async def process(self, pdf_bytes: bytes, document_id: str, document_hash: Optional[str] = None,
+                      hash_future=None) -> Dict[str, str]:
         t0 = time.perf_counter()
         try:
+            loop = asyncio.get_running_loop()
+            # extraction does not read the digest: it starts first, and a digest still on its way (the hash thread
+            # runs a few pieces behind the upload) is awaited beside it, before the 'processing' record is written
+            fut = loop.run_in_executor(self.extract_pool, self.extractor.extract, pdf_bytes, document_id, document_hash)
+            if hash_future is not None:
+                try:
+                    document_hash = await asyncio.wrap_future(hash_future)
+                except Exception:  # noqa: BLE001 - the streamed digest is an optimisation, never a reason to fail
+                    document_hash = await self._io(lambda: hashlib.sha256(pdf_bytes).hexdigest())
             await self._io(self.status.update, document_id, {
                 "status": "processing", "document_hash": document_hash, "started_at": _now(), "owner": self.node_id})
-            loop = asyncio.get_running_loop()
-            fut = loop.run_in_executor(self.extract_pool, self.extractor.extract, pdf_bytes, document_id, document_hash)
             try:
                 result = await asyncio.wait_for(fut, timeout=self.deadline_s)
             except asyncio.TimeoutError:
@@ -146,4 +159,5 @@ class JobManager:
 
     def shutdown(self) -> None:
         self.io_pool.shutdown(wait=False)
+        self.hash_pool.shutdown(wait=False)
         self.extract_pool.shutdown(wait=False)

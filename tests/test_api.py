@@ -281,6 +281,64 @@ def test_streaming_form_matches_one_shot_parser_at_any_chunking():
             assert form.sha256_hex() == hashlib.sha256(data).hexdigest()
 
 
+def test_streaming_form_can_leave_the_hash_thread_running():
+    """``finish(defer_hash=True)`` returns while the last pieces are still being hashed; the future carries the digest."""
+    import hashlib
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+
+    from distributed_llms_amd.api.multipart import StreamingForm, encode_multipart
+
+    data = bytes(range(256)) * 400
+    body, ctype = encode_multipart({"document_id": "doc-1"}, {"file": ("a.pdf", data, "application/pdf")})
+    pool = ThreadPoolExecutor(2)
+    gate = threading.Event()
+    pool.submit(gate.wait)                      # both hash workers are held up: the digest cannot be ready at finish()
+    pool.submit(gate.wait)
+    form = StreamingForm(ctype, 1 << 20, len(body), hash_pool=pool)
+    form.HASH_PIECE = 4096
+    for k in range(0, len(body), 10_000):
+        form.feed(body[k : k + 10_000])
+    parts = form.finish(defer_hash=True)
+    fut = form.sha256_pending()
+    assert fut is not None and not fut.done()
+    assert bytes(next(p for p in parts if p.is_file).data) == data
+    gate.set()
+    assert fut.result(timeout=10) == hashlib.sha256(data).hexdigest()
+    assert form.sha256_hex() == hashlib.sha256(data).hexdigest()
+    # without a streamed hash there is nothing to wait for
+    form2 = StreamingForm(ctype, 1 << 20, None, hash_pool=pool)
+    form2.feed(body)
+    form2.finish(defer_hash=True)
+    assert form2.sha256_pending() is None and form2.sha256_hex() == hashlib.sha256(data).hexdigest()
+
+
+def test_job_started_with_a_pending_digest_records_it(ctx):
+    """A job handed a digest future starts extraction at once and writes the digest with its status records."""
+    import asyncio
+    from concurrent.futures import Future
+
+    from distributed_llms_amd.jobs.manager import JobManager
+    from distributed_llms_amd.store.results import ErrorSink
+
+    settings, status, results = ctx
+    jobs = JobManager(status, results, ErrorSink(settings.output_dir), StubExtractor(), node_id="test-node")
+    fut: Future = Future()
+
+    async def run():
+        assert await jobs.claim("late-hash", None, "a.pdf") is None
+        task = jobs.start(b"%PDF-1.4 late digest", "late-hash", None, hash_future=fut)
+        await asyncio.sleep(0.05)
+        assert jobs.status.get("late-hash")["status"] == "queued"      # 'processing' waits for the digest
+        fut.set_result("ab" * 32)
+        return await task
+
+    out = asyncio.run(run())
+    assert out["status"] == "completed"
+    rec = jobs.status.get("late-hash")
+    assert rec["status"] == "completed" and rec["document_hash"] == "ab" * 32
+
+
 def test_upload_cap_holds_without_content_length(ctx, monkeypatch):
     """A chunked upload (no Content-Length) is cut off at the cap while it streams, not buffered to the end."""
     import distributed_llms_amd.api.app as appmod
