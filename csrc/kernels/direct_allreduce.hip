@@ -20,6 +20,12 @@
 // acquire, vmcnt(0), workgroup barrier, plain loads.  Spins are bounded: a rank whose peer never
 // arrives sets a status word and leaves, so the grid always drains.
 //
+// Registered regions: a caller that allocates its buffers with dlamd_dar_alloc (gradient buckets) registers them
+// once, and dlamd_dar_allreduce_region reduces them IN PLACE - no staging copy.  Without the second slot the call
+// needs one more barrier: a rank may rewrite its buffer (next backward) only after every peer has finished reading
+// it, so in-place calls end with a third barrier; the one-shot form holds its sums in registers across a barrier
+// (every peer has read) before it stores them.
+//
 // The reference has no collective of any kind; this is new for DP recognizer training.
 #include "common.h"
 #include <stdlib.h>
@@ -28,6 +34,8 @@
 #define DAR_MAX_WORLD 8
 #define DAR_THREADS 512
 #define DAR_FLAG_STRIDE 8   // uint32 words per (phase, block): one per source rank
+#define DAR_PHASES 3        // barriers per call: inputs complete, shards reduced, (in place) shards copied
+#define DAR_MAX_REGIONS 64
 
 struct DarArgs {
   const char* peer_data[DAR_MAX_WORLD];   // slot base of each rank's data region (own entry = local pointer)
@@ -40,6 +48,7 @@ struct DarArgs {
   uint32_t spin_limit;
   float scale;
   uint32_t* status;
+  int inplace;                            // peer_data are the callers' own buffers: out == own_data, end barrier
 };
 
 __device__ __forceinline__ void dar_barrier(const DarArgs& a, int phase, bool release) {
@@ -129,6 +138,15 @@ __global__ __launch_bounds__(DAR_THREADS) void dar_allreduce_kernel(DarArgs a) {
   u32x4* out = (u32x4*)a.out;
   dar_barrier(a, 0, true);   // every peer's input slot is complete
   if constexpr (ONE_SHOT) {
+    if (a.inplace) {
+      // out is the buffer the peers read: sum first, store after every peer has read (host: nvec <= grid threads)
+      const bool have = first < a.nvec;
+      u32x4 r = {0u, 0u, 0u, 0u};
+      if (have) r = dar_sum_at<BF16, WORLD>(a, first);
+      dar_barrier(a, 1, true);
+      if (have) out[first] = r;
+      return;
+    }
     for (long i = first; i < a.nvec; i += stride) out[i] = dar_sum_at<BF16, WORLD>(a, i);
   } else {
     const int world = WORLD > 0 ? WORLD : a.world;
@@ -138,7 +156,7 @@ __global__ __launch_bounds__(DAR_THREADS) void dar_allreduce_kernel(DarArgs a) {
     for (long i = lo + first; i < hi; i += stride) {
       u32x4 r = dar_sum_at<BF16, WORLD>(a, i);
       *(u32x4*)(a.own_data + i * 16) = r;
-      out[i] = r;
+      if (!a.inplace) out[i] = r;
     }
     dar_barrier(a, 1, true);   // every peer's reduced shard is stored and released
     for (int s = 1; s < world; ++s) {
@@ -148,6 +166,7 @@ __global__ __launch_bounds__(DAR_THREADS) void dar_allreduce_kernel(DarArgs a) {
       const char* src = a.peer_data[p];
       for (long i = plo + first; i < phi; i += stride) out[i] = *(const u32x4*)(src + i * 16);
     }
+    if (a.inplace) dar_barrier(a, 2, true);   // every peer has copied this rank's shard: the buffer may be rewritten
   }
 }
 
@@ -155,7 +174,7 @@ struct DarContext {
   int rank = 0, world = 1, blocks = 0, device = 0;
   long max_bytes = 0;
   char* data = nullptr;          // 2 * max_bytes
-  uint32_t* flags = nullptr;     // 2 phases * blocks * DAR_FLAG_STRIDE (+ status word at the end, local use)
+  uint32_t* flags = nullptr;     // DAR_PHASES * blocks * DAR_FLAG_STRIDE words
   size_t flag_bytes = 0;
   bool flags_uncached = false;
   char* peer_data[DAR_MAX_WORLD] = {};
@@ -163,12 +182,15 @@ struct DarContext {
   bool imported[DAR_MAX_WORLD] = {};
   uint32_t* status = nullptr;    // separate local allocation
   uint32_t seq = 0;
+  int nregions = 0;
+  char* region[DAR_MAX_REGIONS][DAR_MAX_WORLD] = {};   // registered caller buffers: [id][rank]
+  long region_bytes[DAR_MAX_REGIONS] = {};
   uint32_t spin_limit = 64u << 20;   // polls before a barrier gives up on a peer: tens of seconds (ranks skew by whole
                                      // data-loader stalls and checkpoint writes; DLAMD_DAR_SPIN_LIMIT / set_spin_limit override)
 };
 
 static size_t dar_flag_bytes(int blocks) {
-  size_t n = (size_t)2 * blocks * DAR_FLAG_STRIDE * sizeof(uint32_t);
+  size_t n = (size_t)DAR_PHASES * blocks * DAR_FLAG_STRIDE * sizeof(uint32_t);
   return (n + 4095) / 4096 * 4096;
 }
 
@@ -250,7 +272,7 @@ extern "C" int dlamd_dar_set_spin_limit(void* ctx, long n) {
   return 0;
 }
 
-// Blocking read of the status word: 0 ok, 1 / 2 = a peer never reached the first / second barrier.
+// Blocking read of the status word: 0 ok, 1 / 2 / 3 = a peer never reached the first / second / third barrier.
 extern "C" int dlamd_dar_status(void* ctx) {
   DarContext* c = (DarContext*)ctx;
   if (!c) return -1;
@@ -270,6 +292,32 @@ static void dar_launch(const DarArgs& a, int world, int blocks, hipStream_t st) 
   }
 }
 
+static int dar_run(DarContext* c, char* const* peer_base, long base_off, void* out, long bytes, int dtype, float scale,
+                   int algo, bool inplace, hipStream_t st) {
+  DarArgs a;
+  for (int p = 0; p < DAR_MAX_WORLD; ++p) {
+    a.peer_data[p] = p < c->world ? peer_base[p] + base_off : nullptr;
+    a.peer_flags[p] = p < c->world ? c->peer_flags[p] : nullptr;
+  }
+  a.own_data = peer_base[c->rank] + base_off;
+  a.out = out;
+  a.nvec = bytes / 16;
+  a.rank = c->rank; a.world = c->world; a.nblocks = c->blocks;
+  a.seq = c->seq;
+  a.spin_limit = c->spin_limit;
+  a.scale = scale;
+  a.status = c->status;
+  a.inplace = inplace ? 1 : 0;
+  if (dtype == 0) {
+    if (algo == 1) dar_launch<true, true>(a, c->world, c->blocks, st);
+    else dar_launch<true, false>(a, c->world, c->blocks, st);
+  } else {
+    if (algo == 1) dar_launch<false, true>(a, c->world, c->blocks, st);
+    else dar_launch<false, false>(a, c->world, c->blocks, st);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -8;
+}
+
 // dtype: 0 = bf16, 1 = fp32.  algo: 0 auto, 1 one-shot, 2 two-shot.  `in` may equal `out`.
 // Collective contract: every rank calls with the same count / dtype / algo, in the same order.
 extern "C" int dlamd_dar_allreduce(void* ctx, const void* in, void* out, long count, int dtype, float scale, int algo,
@@ -287,27 +335,68 @@ extern "C" int dlamd_dar_allreduce(void* ctx, const void* in, void* out, long co
   c->seq += 1;
   const long slot_off = (long)(c->seq & 1u) * c->max_bytes;
   if (hipMemcpyAsync(c->data + slot_off, in, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return -7;
-  DarArgs a;
-  for (int p = 0; p < DAR_MAX_WORLD; ++p) {
-    a.peer_data[p] = p < c->world ? c->peer_data[p] + slot_off : nullptr;
-    a.peer_flags[p] = p < c->world ? c->peer_flags[p] : nullptr;
-  }
-  a.own_data = c->data + slot_off;
-  a.out = out;
-  a.nvec = bytes / 16;
-  a.rank = c->rank; a.world = c->world; a.nblocks = c->blocks;
-  a.seq = c->seq;
-  a.spin_limit = c->spin_limit;
-  a.scale = scale;
-  a.status = c->status;
-  if (dtype == 0) {
-    if (algo == 1) dar_launch<true, true>(a, c->world, c->blocks, st);
-    else dar_launch<true, false>(a, c->world, c->blocks, st);
-  } else {
-    if (algo == 1) dar_launch<false, true>(a, c->world, c->blocks, st);
-    else dar_launch<false, false>(a, c->world, c->blocks, st);
-  }
-  return hipGetLastError() == hipSuccess ? 0 : -8;
+  return dar_run(c, c->peer_data, slot_off, out, bytes, dtype, scale, algo, false, st);
+}
+
+// ---- registered regions: buffers the caller owns (gradient buckets), reduced in place
+extern "C" int dlamd_dar_alloc(long bytes, void** out) {
+  if (!out || bytes <= 0) return -1;
+  void* p = nullptr;
+  if (hipMalloc(&p, (size_t)bytes) != hipSuccess) { (void)hipGetLastError(); return -2; }
+  if (hipMemset(p, 0, (size_t)bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return -3; }
+  *out = p;
+  return 0;
+}
+
+extern "C" int dlamd_dar_free(void* p) {
+  if (!p) return -1;
+  return hipFree(p) == hipSuccess ? 0 : -2;
+}
+
+// base: an allocation of dlamd_dar_alloc (IPC handles exist per allocation, not per sub-range).  Returns the region id
+// (the same on every rank when all register in the same order) and writes the 64-byte handle for the peers.
+extern "C" int dlamd_dar_register(void* ctx, void* base, long bytes, void* handle) {
+  DarContext* c = (DarContext*)ctx;
+  if (!c || !base || !handle || bytes <= 0 || (bytes & 15) || ((uintptr_t)base & 15)) return -1;
+  if (c->nregions >= DAR_MAX_REGIONS) return -2;
+  hipIpcMemHandle_t h;
+  if (hipIpcGetMemHandle(&h, base) != hipSuccess) { (void)hipGetLastError(); return -3; }
+  memcpy(handle, &h, sizeof(h));
+  const int id = c->nregions++;
+  c->region[id][c->rank] = (char*)base;
+  c->region_bytes[id] = bytes;
+  return id;
+}
+
+extern "C" int dlamd_dar_register_peer(void* ctx, int region, int peer, const void* handle) {
+  DarContext* c = (DarContext*)ctx;
+  if (!c || !handle || region < 0 || region >= c->nregions || peer < 0 || peer >= c->world || peer == c->rank) return -1;
+  if (c->region[region][peer]) return -2;
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, sizeof(h));
+  void* d = nullptr;
+  if (hipIpcOpenMemHandle(&d, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return -3; }
+  c->region[region][peer] = (char*)d;
+  return 0;
+}
+
+// In-place all-reduce of the first `count` elements of a registered region (every rank: same region / count / dtype).
+extern "C" int dlamd_dar_allreduce_region(void* ctx, int region, long count, int dtype, float scale, int algo,
+                                          hipStream_t st) {
+  DarContext* c = (DarContext*)ctx;
+  if (!c || region < 0 || region >= c->nregions || count <= 0) return -1;
+  if (dtype != 0 && dtype != 1) return -2;
+  const long bytes = count * (dtype == 0 ? 2 : 4);
+  if ((bytes & 15) || bytes > c->region_bytes[region]) return -3;
+  for (int p = 0; p < c->world; ++p)
+    if (!c->imported[p] || !c->region[region][p]) return -5;
+  // the one-shot form keeps one 16-byte vector per thread in registers across its barrier
+  const long grid_vecs = (long)c->blocks * DAR_THREADS;
+  if (algo == 0) algo = (bytes <= (512l << 10) && bytes / 16 <= grid_vecs) ? 1 : 2;
+  if (algo != 1 && algo != 2) return -6;
+  if (algo == 1 && bytes / 16 > grid_vecs) return -7;
+  c->seq += 1;
+  return dar_run(c, c->region[region], 0, c->region[region][c->rank], bytes, dtype, scale, algo, true, st);
 }
 
 extern "C" int dlamd_dar_destroy(void* ctx) {
@@ -318,6 +407,8 @@ extern "C" int dlamd_dar_destroy(void* ctx) {
     if (p == c->rank || !c->imported[p]) continue;
     (void)hipIpcCloseMemHandle(c->peer_data[p]);
     (void)hipIpcCloseMemHandle(c->peer_flags[p]);
+    for (int r = 0; r < c->nregions; ++r)
+      if (c->region[r][p]) (void)hipIpcCloseMemHandle(c->region[r][p]);
   }
   (void)hipFree(c->status);
   (void)hipFree(c->flags);

@@ -114,4 +114,9 @@ def _declare(l: ctypes.CDLL) -> None:
     sig("dlamd_dar_set_spin_limit", [vp, ll])
     sig("dlamd_dar_allreduce", [vp, vp, vp, ll, i, f, i, vp])
     sig("dlamd_dar_destroy", [vp])
+    sig("dlamd_dar_alloc", [ll, vp])
+    sig("dlamd_dar_free", [vp])
+    sig("dlamd_dar_register", [vp, vp, ll, vp])
+    sig("dlamd_dar_register_peer", [vp, i, i, vp])
+    sig("dlamd_dar_allreduce_region", [vp, i, ll, i, f, i, vp])
     sig("dlamd_embed_rows", [vp, vp, vp, vp, vp, ll, i, i, i, i, f, vp])

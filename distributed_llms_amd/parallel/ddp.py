@@ -48,7 +48,10 @@ class FlatBuckets:
     """Re-homes parameters (and their .grad) into contiguous flat buffers, bucketed in reverse
     registration order (= the order gradients become ready in backward)."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, pad_to: int = 1):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, pad_to: int = 1,
+                 grad_alloc=None):
+        """``grad_alloc(numel, dtype)`` -> zero-filled flat tensor: where a bucket's gradient buffer comes from when it
+        must live in memory of a particular kind (an IPC-exportable allocation for the direct all-reduce)."""
         plist = [p for p in params if p.requires_grad]
         assert plist, "no trainable parameters"
         dtype, device = plist[0].dtype, plist[0].device
@@ -74,7 +77,8 @@ class FlatBuckets:
             used = total
             total = _align(total, max(pad_to, 4))
             fp = torch.zeros(total, dtype=dtype, device=device)
-            fg = torch.zeros(total, dtype=dtype, device=device)
+            fg = torch.zeros(total, dtype=dtype, device=device) if grad_alloc is None else grad_alloc(total, dtype)
+            assert fg.numel() == total and fg.dtype == dtype and fg.device == device
             for p, o in zip(g, offs):
                 fp[o : o + p.numel()].copy_(p.data.reshape(-1))
                 p.data = fp[o : o + p.numel()].view_as(p.data)
@@ -106,25 +110,42 @@ class BucketedDDP:
     """Gradient averaging across the data-parallel group, overlapped with backward."""
 
     def __init__(self, module: torch.nn.Module, bucket_mb: float = 64.0, mode: str = "allreduce",
-                 group: Optional[dist.ProcessGroup] = None, broadcast_params: bool = True):
+                 group: Optional[dist.ProcessGroup] = None, broadcast_params: bool = True,
+                 register_buckets: bool = True):
+        """``register_buckets`` (direct mode): the flat gradient buckets are allocated as IPC-exportable buffers and
+        registered with the all-reduce, which then reduces them in place - the peers read a gradient from where
+        autograd accumulated it.  False stages every bucket through the all-reduce's own buffers (one more
+        device-to-device copy per bucket)."""
         assert mode in ("allreduce", "rs_ag", "direct")
         self.module = module
         self.mode = mode
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.flat = FlatBuckets(module.parameters(), int(bucket_mb * (1 << 20)), pad_to=max(1, self.world) * 8)
         self._direct = None
         self._comm_stream = None
-        if mode == "direct":
-            if self.flat.device.type == "cuda" and 2 <= self.world <= 8:
+        self.registered = False
+        plist = [p for p in module.parameters() if p.requires_grad]
+        device = plist[0].device if plist else torch.device("cpu")
+        bucket_bytes, pad_to = int(bucket_mb * (1 << 20)), max(1, self.world) * 8
+        if mode == "direct" and not (device.type == "cuda" and 2 <= self.world <= 8):
+            self.mode = mode = "allreduce"
+        if mode == "direct" and register_buckets:
+            from .direct import DirectAllReduce
+
+            self._direct = DirectAllReduce(4096, group=group, device=device)   # no staging buffers to speak of
+            self.flat = FlatBuckets(module.parameters(), bucket_bytes, pad_to=pad_to, grad_alloc=self._direct.alloc)
+            self._direct.register([b.flat_grad for b in self.flat.buckets])
+            self.registered = True
+        else:
+            self.flat = FlatBuckets(module.parameters(), bucket_bytes, pad_to=pad_to)
+            if mode == "direct":
                 from .direct import DirectAllReduce
 
                 big = max(b.flat_grad.numel() * b.flat_grad.element_size() for b in self.flat.buckets)
                 self._direct = DirectAllReduce(big, group=group, device=self.flat.device)
-                self._comm_stream = torch.cuda.Stream(self.flat.device)
-            else:
-                self.mode = "allreduce"
+        if self._direct is not None:
+            self._comm_stream = torch.cuda.Stream(self.flat.device)
         self.comm_bytes = 0
         self.comm_calls = 0
         if self.world > 1 and broadcast_params:
@@ -162,7 +183,10 @@ class BucketedDDP:
         if self.mode == "direct":
             self._comm_stream.wait_stream(torch.cuda.current_stream(self.flat.device))
             with torch.cuda.stream(self._comm_stream):
-                self._direct.all_reduce_(b.flat_grad, scale=1.0 / self.world)
+                if self.registered:
+                    self._direct.all_reduce_region_(b.flat_grad, scale=1.0 / self.world)
+                else:
+                    self._direct.all_reduce_(b.flat_grad, scale=1.0 / self.world)
             self.comm_bytes += b.flat_grad.numel() * b.flat_grad.element_size()
             self.comm_calls += 1
             return

@@ -11,8 +11,14 @@ process group (``all_gather_object``), and every rank maps its peers' buffers.
 
 The reference has no collective backend at all; nothing to cite there.
 
-Collective contract: every rank calls ``all_reduce_`` with the same shape / dtype / algo in the same
-order.  Results are bitwise identical on every rank (fixed summation order, fp32 accumulation).
+Two ways in: ``all_reduce_(tensor)`` stages any tensor through the context's own exported buffers (one
+device-to-device copy per call), and ``alloc`` / ``register`` / ``all_reduce_region_`` reduce buffers the caller
+allocated through this module IN PLACE - what ``BucketedDDP`` does with its flat gradient buckets, so a gradient is
+read by the peers from where autograd wrote it.
+
+Collective contract: every rank calls ``all_reduce_`` / ``register`` / ``all_reduce_region_`` with the same
+shape / dtype / algo in the same order.  Results are bitwise identical on every rank (fixed summation order, fp32
+accumulation).
 """
 from __future__ import annotations
 
@@ -35,6 +41,35 @@ class DirectAllReduceError(RuntimeError):
 def supported(t: torch.Tensor) -> bool:
     return (t.is_cuda and t.is_contiguous() and t.dtype in (torch.bfloat16, torch.float32)
             and (t.numel() * t.element_size()) % 16 == 0 and t.data_ptr() % 16 == 0)
+
+
+class _IpcAllocation:
+    """Device memory from ``hipMalloc`` (exportable as a whole through ``hipIpcGetMemHandle``, which allocations carved
+    out of PyTorch's caching allocator are not), presented to ``torch.as_tensor`` through the array interface.  The
+    tensor keeps this object alive; the memory is released with it."""
+
+    def __init__(self, lib, nbytes: int, device: torch.device):
+        self._lib = lib
+        self.nbytes = int(nbytes)
+        self.device = device
+        p = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            rc = lib.dlamd_dar_alloc(self.nbytes, ctypes.byref(p))
+        if rc != 0 or not p.value:
+            raise DirectAllReduceError(f"hipMalloc of {self.nbytes} bytes for a registered bucket failed ({rc})")
+        self.ptr = int(p.value)
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2, "strides": None}
+
+    def __del__(self):
+        ptr, self.ptr = getattr(self, "ptr", 0), 0
+        if ptr:
+            try:
+                self._lib.dlamd_dar_free(ctypes.c_void_p(ptr))
+            except Exception:  # noqa: BLE001 - interpreter shutdown: the driver reclaims the memory with the process
+                pass
 
 
 class DirectAllReduce:
@@ -84,6 +119,7 @@ class DirectAllReduce:
                                                "is HSA_ENABLE_IPC_MODE_LEGACY=0 exported before the first HIP call?")
         dist.barrier(group=group)   # nobody launches before every rank has mapped every peer
         self.calls = 0
+        self._regions = {}          # data_ptr of a registered tensor -> (region id, bytes, allocation)
 
     @property
     def flags_uncached(self) -> bool:
@@ -108,12 +144,71 @@ class DirectAllReduce:
         self.calls += 1
         return dst
 
+    # ------------------------------------------------------------------ registered buffers (reduced in place)
+    def alloc(self, numel: int, dtype: torch.dtype) -> torch.Tensor:
+        """A zero-filled 1-d tensor in its own IPC-exportable allocation (size rounded up to 16 bytes)."""
+        esz = torch.empty((), dtype=dtype).element_size()
+        nbytes = (int(numel) * esz + 15) // 16 * 16
+        a = _IpcAllocation(self._l, nbytes, self.device)
+        raw = torch.as_tensor(a, device=self.device)
+        if raw.data_ptr() != a.ptr:
+            raise DirectAllReduceError("torch copied the IPC allocation instead of aliasing it")
+        t = raw.view(dtype)[:numel]
+        t._dlamd_ipc = a            # found again by register()
+        return t
+
+    def register(self, tensors) -> list:
+        """Collective: export each tensor's allocation (from ``alloc``) and map every peer's.  -> region ids."""
+        mine, ids = [], []
+        with torch.cuda.device(self.device):
+            for t in tensors:
+                a = getattr(t, "_dlamd_ipc", None)
+                if a is None or t.data_ptr() != a.ptr:
+                    raise DirectAllReduceError("register() takes tensors returned by alloc()")
+                h = ctypes.create_string_buffer(64)
+                rid = self._l.dlamd_dar_register(self._ctx, ctypes.c_void_p(a.ptr), a.nbytes, h)
+                if rid < 0:
+                    raise DirectAllReduceError(f"rank {self.rank}: registering a {a.nbytes}-byte buffer failed ({rid})")
+                ids.append(rid)
+                mine.append((rid, a.nbytes, bytes(h.raw)))
+                self._regions[a.ptr] = (rid, a.nbytes, a)
+            everyone = [None] * self.world
+            dist.all_gather_object(everyone, mine, group=self.group)
+            if len({tuple((r, n) for r, n, _ in regs) for regs in everyone}) != 1:
+                raise DirectAllReduceError("ranks registered different buffers (ids / sizes differ)")
+            for p, regs in enumerate(everyone):
+                if p == self.rank:
+                    continue
+                for rid, _, h in regs:
+                    rc = self._l.dlamd_dar_register_peer(self._ctx, rid, p, ctypes.create_string_buffer(h, 64))
+                    if rc != 0:
+                        raise DirectAllReduceError(f"rank {self.rank}: mapping region {rid} of rank {p} failed ({rc})")
+        dist.barrier(group=self.group)
+        return ids
+
+    def region_of(self, t: torch.Tensor) -> Optional[int]:
+        r = self._regions.get(t.data_ptr())
+        return None if r is None else r[0]
+
+    def all_reduce_region_(self, t: torch.Tensor, scale: float = 1.0, algo: str = "auto") -> torch.Tensor:
+        """Sum a registered tensor over the group in place, on the current HIP stream, without a staging copy."""
+        r = self._regions.get(t.data_ptr())
+        if r is None:
+            raise DirectAllReduceError("tensor is not registered (alloc + register first)")
+        if not supported(t) or t.numel() * t.element_size() > r[1]:
+            raise DirectAllReduceError("registered tensor must be contiguous bf16/fp32 with a multiple of 16 bytes")
+        rc = self._l.dlamd_dar_allreduce_region(self._ctx, r[0], t.numel(), 0 if t.dtype == torch.bfloat16 else 1,
+                                                float(scale), ALGOS[algo], self._loader.stream_ptr())
+        self._loader.check(rc, "dlamd_dar_allreduce_region")
+        self.calls += 1
+        return t
+
     def set_spin_limit(self, polls: int) -> None:
         """Polls a barrier makes before it gives up on a peer (default 64 Mi, tens of seconds; env DLAMD_DAR_SPIN_LIMIT)."""
         self._loader.check(self._l.dlamd_dar_set_spin_limit(self._ctx, int(polls)), "dlamd_dar_set_spin_limit")
 
     def status(self) -> int:
-        """Blocking: 0 ok; 1 / 2 = some peer never reached the first / second barrier of a call (bounded spin ran out)."""
+        """Blocking: 0 ok; 1 / 2 / 3 = some peer never reached that barrier of a call (bounded spin ran out)."""
         return int(self._l.dlamd_dar_status(self._ctx))
 
     def check(self) -> None:
@@ -129,3 +224,4 @@ class DirectAllReduce:
                 pass
             self._l.dlamd_dar_destroy(self._ctx)
             self._ctx = None
+            self._regions = {}      # the tensors keep their allocations; only the peers' mappings are gone

@@ -103,6 +103,70 @@ def test_direct_allreduce_bounded_spin_reports_missing_peer():
     assert res[0]["status"] == 0 and res[0]["starved_status"] == 1
 
 
+def _region_rank(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", DLAMD_DAR_SPIN_LIMIT=str(1 << 22))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from distributed_llms_amd.parallel.direct import DirectAllReduce, DirectAllReduceError
+
+    ar = DirectAllReduce(max_bytes=4096, blocks=32)
+    # one-shot holds one 16-byte vector per thread: 32 blocks x 512 threads = 256 KiB at most
+    cases = [(torch.float32, 4096, "one_shot"), (torch.float32, 4096, "two_shot"), (torch.bfloat16, 8, "auto"),
+             (torch.bfloat16, 1 << 17, "one_shot"), (torch.bfloat16, (1 << 20) + 8 * 37, "two_shot"),
+             (torch.float32, (2 << 20) - 4, "auto"), (torch.bfloat16, 4 << 20, "auto")]
+    bufs = [ar.alloc(n, dtype) for dtype, n, _ in cases]
+    ids = ar.register(bufs[:3]) + ar.register(bufs[3:])          # regions can be added later
+    res = {"ids": ids, "zeroed": all(bool((b == 0).all()) for b in bufs), "cases": []}
+    g = torch.Generator().manual_seed(4321)
+    for rep in range(3):
+        for (dtype, n, algo), buf in zip(cases, bufs):
+            # two reductions back to back with no host synchronisation: the refill of the second runs as soon as this
+            # rank's first kernel has ended, i.e. only after every peer has read the first input
+            parts1 = [(torch.randn(n, generator=g) * (p + 1)).to(dtype) for p in range(world)]
+            parts2 = [(torch.randn(n, generator=g) - p).to(dtype) for p in range(world)]
+            x1, x2 = parts1[rank].cuda(), parts2[rank].cuda()
+            first = torch.empty_like(buf)
+            scale = 1.0 / world if rep == 1 else 1.0
+            buf.copy_(x1)
+            ar.all_reduce_region_(buf, scale=scale, algo=algo)
+            first.copy_(buf)
+            buf.copy_(x2)
+            ar.all_reduce_region_(buf, scale=scale, algo=algo)
+            torch.cuda.synchronize()
+            ok = torch.equal(first.cpu(), _oracle(parts1, scale, dtype)) and torch.equal(buf.cpu(), _oracle(parts2, scale, dtype))
+            res["cases"].append((str(dtype), n, algo, rep, bool(ok)))
+    res["status"] = ar.status()
+    try:
+        ar.all_reduce_region_(torch.zeros(64, device="cuda"))
+        res["unregistered"] = "accepted"
+    except DirectAllReduceError:
+        res["unregistered"] = "refused"
+    try:
+        ar.all_reduce_region_(bufs[4], algo="one_shot")           # larger than the one-shot form can hold
+        res["oversized_one_shot"] = "accepted"
+    except Exception:  # noqa: BLE001
+        res["oversized_one_shot"] = "refused"
+    torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    ar.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_registered_buffers_are_reduced_in_place(world):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_region_rank, args=(world, _free_port(), d), nprocs=world, join=True)
+        res = [torch.load(os.path.join(d, f"r{r}.pt"), weights_only=True) for r in range(world)]
+    for r in res:
+        assert r["ids"] == list(range(7)) and r["zeroed"]
+        bad = [c for c in r["cases"] if not c[4]]
+        assert not bad, bad[:4]
+        assert r["status"] == 0 and r["unregistered"] == "refused" and r["oversized_one_shot"] == "refused"
+    assert len(res[0]["cases"]) == 21
+
+
 def _ddp_rank(rank, world, port, out_dir, mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -113,8 +177,12 @@ def _ddp_rank(rank, world, port, out_dir, mode):
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.ReLU(), torch.nn.Linear(256, 256), torch.nn.ReLU(),
                               torch.nn.Linear(256, 8)).cuda()
-    ddp = BucketedDDP(net, bucket_mb=0.1, mode=mode)
+    ddp = BucketedDDP(net, bucket_mb=0.1, mode=mode.split("_")[0], register_buckets=mode != "direct_staged")
     assert len(ddp.flat.buckets) > 1
+    if ddp._direct is not None:
+        # registered: every gradient bucket is a region of the all-reduce (reduced where autograd wrote it)
+        regions = [ddp._direct.region_of(b.flat_grad) for b in ddp.flat.buckets]
+        assert (regions == list(range(len(regions)))) == (mode == "direct") and ddp.registered == (mode == "direct")
     g = torch.Generator().manual_seed(7 + rank)
     for _ in range(3):
         ddp.zero_grad()
@@ -126,6 +194,7 @@ def _ddp_rank(rank, world, port, out_dir, mode):
                 b.flat_param.add_(b.flat_grad, alpha=-0.1)
     torch.cuda.synchronize()
     torch.save({"flat": torch.cat([b.flat_param for b in ddp.flat.buckets]).cpu(), "mode": ddp.mode,
+                "calls": ddp._direct.calls if ddp._direct is not None else 0,
                 "status": ddp._direct.status() if ddp._direct is not None else 0}, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -134,13 +203,15 @@ def _ddp_rank(rank, world, port, out_dir, mode):
 @pytest.mark.gpu
 def test_bucketed_ddp_direct_mode_equals_allreduce_mode():
     out = {}
-    for mode in ("direct", "allreduce"):
+    for mode in ("direct", "direct_staged", "allreduce"):
         with tempfile.TemporaryDirectory() as d:
             mp.spawn(_ddp_rank, args=(2, _free_port(), d, mode), nprocs=2, join=True)
             out[mode] = [torch.load(os.path.join(d, f"r{r}.pt"), weights_only=True) for r in range(2)]
-    assert out["direct"][0]["mode"] == "direct" and out["direct"][0]["status"] == 0
-    assert torch.equal(out["direct"][0]["flat"], out["direct"][1]["flat"]), "ranks must stay bitwise in step"
-    torch.testing.assert_close(out["direct"][0]["flat"], out["allreduce"][0]["flat"], rtol=1e-5, atol=1e-6)
+    for mode in ("direct", "direct_staged"):
+        assert out[mode][0]["mode"] == "direct" and out[mode][0]["status"] == 0 and out[mode][0]["calls"] > 0
+        assert torch.equal(out[mode][0]["flat"], out[mode][1]["flat"]), "ranks must stay bitwise in step"
+        torch.testing.assert_close(out[mode][0]["flat"], out["allreduce"][0]["flat"], rtol=1e-5, atol=1e-6)
+    assert torch.equal(out["direct"][0]["flat"], out["direct_staged"][0]["flat"]), "same kernel, same summation order"
 
 
 def test_direct_mode_falls_back_on_cpu_groups():
