@@ -53,6 +53,13 @@ def run(rank, world, shared_gpu, iters, max_mb, blocks):
             us = _time(lambda: ar.all_reduce_(x, scale=1.0 / world, algo=algo), iters)
             row[algo + "_us"] = round(us, 1)
             row[algo + "_algbw_GBps"] = round(nbytes / us / 1e3, 1)
+        # the same bucket as a registered region, reduced in place (what BucketedDDP does): no staging copy
+        reg = ar.alloc(nbytes // 2, torch.bfloat16)
+        ar.register([reg])
+        reg.copy_(x)
+        us = _time(lambda: ar.all_reduce_region_(reg, scale=1.0 / world), iters)
+        row["in_place_us"] = round(us, 1)
+        row["in_place_algbw_GBps"] = round(nbytes / us / 1e3, 1)
         if not shared_gpu:
             us = _time(lambda: dist.all_reduce(x), iters)
             row["rccl_us"] = round(us, 1)
@@ -99,6 +106,10 @@ def contract(args):
         algos = {"rccl": (lambda: dist.all_reduce(x)) if world > 1 else (lambda: x.mul_(1.0))}
         if ar is not None:
             algos["direct_two_shot"] = lambda: ar.all_reduce_(x, scale=1.0 / world, algo="two_shot")
+            reg = ar.alloc(nbytes // 2, torch.bfloat16)
+            ar.register([reg])
+            reg.copy_(x)
+            algos["direct_in_place"] = lambda: ar.all_reduce_region_(reg, scale=1.0 / world)
         sync = torch.cuda.synchronize
         dtype = "bf16"
     res = {}
