@@ -31,7 +31,24 @@ IO_THREADS = 10  # ocr_service.py:44
 
 
 def configure_logging(level: int = logging.INFO) -> None:
-    logging.basicConfig(level=level, format=LOG_FORMAT)
+    """Root logger -> stderr in the reference's format (like ``logging.basicConfig``: nothing happens when the root
+    logger already has handlers).  Records travel through a queue to one writer thread, so a request or job thread
+    never waits for the stream lock or the write (four INFO lines per document, dozens of threads)."""
+    import atexit
+    import logging.handlers
+    import queue
+
+    root = logging.getLogger()
+    if root.handlers:
+        return
+    stream = logging.StreamHandler()
+    stream.setFormatter(logging.Formatter(LOG_FORMAT))
+    q: "queue.SimpleQueue" = queue.SimpleQueue()
+    listener = logging.handlers.QueueListener(q, stream)
+    listener.start()
+    atexit.register(listener.stop)
+    root.addHandler(logging.handlers.QueueHandler(q))
+    root.setLevel(level)
 
 
 def load_dotenv(path: os.PathLike | str = ".env", override: bool = False, environ: Optional[dict] = None) -> Dict[str, str]:
