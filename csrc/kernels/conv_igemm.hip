@@ -1214,8 +1214,11 @@ extern "C" int dlamd_conv2d(const void* x, const void* w, const float* bias, con
   // 8-wave tile halves the weight traffic once more (layer1 0.270 ms, head 0.667).
   if (patch_ok && cfg == 0 && sh == 1 && (Cout <= 64 || (Cout <= 128 && Cin <= 128))) {
     if (Cout <= 64 && (long long)B * a.Ho * a.Wo >= 1000000 && a.Ho >= 16) {
-      // 64 -> 64 on the quarter-scale maps: the resident-filter kernel (0.240 against 0.270 ms on 25 pages)
-      static const bool c64 = [] { const char* e = getenv("DLAMD_CONV_C64"); return !(e && e[0] == '0'); }();
+      // 64 -> 64 on the quarter-scale maps: the resident-filter kernel is 11 % faster alone (0.240 against 0.270 ms
+      // on 25 pages), but it owns its CUs (one wave per SIMD with the whole register file), so in the two-stream
+      // pipeline the other stream's kernels cannot share them: 672 us per call there, bench.py unchanged within
+      // noise (961 against 956 pages/s).  Opt-in: DLAMD_CONV_C64=1.
+      static const bool c64 = [] { const char* e = getenv("DLAMD_CONV_C64"); return e && e[0] == '1'; }();
       if (c64 && Cin == 64 && (Cout & 3) == 0 && a.out_mode == 0 && !a.y_f32 && a.res_mode <= 1 &&
           (a.act == ACT_NONE || a.act == ACT_RELU))
         return launch_c64<16, 16>(a, stream);
