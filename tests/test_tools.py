@@ -46,6 +46,12 @@ def test_language_identification_by_script_and_function_words():
         assert got == want and conf > 0.5, (want, got, conf)
     assert detect("42 17 3.5")[0] == "und" and detect("")[0] == "und" and detect("ok go")[0] == "und"
     assert script_shares("abc абв")["latin"] == 0.5
+    # letters outside the basic plane belong to no listed script but still count as letters; digits and marks do not
+    shares = script_shares("ab \U00020000\U00020001 12 !?")
+    assert shares == {"latin": 0.5}
+    assert script_shares("漢字かな") == {"kana": 0.5, "han": 0.5}
+    # language-specific marks that are not letters still vote (the inverted question mark for Spanish)
+    assert detect("¿Que hora es? ¿Como te llamas? ¿Donde vive el medico de la familia de tu amigo?")[0] == "es"
 
 
 def test_document_result_carries_the_language():

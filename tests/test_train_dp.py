@@ -123,3 +123,25 @@ def test_flat_buckets_views_and_grad_reattach():
     assert all(float(bk.flat_grad.abs().sum()) > 0 for bk in fb.buckets)
     ddp = BucketedDDP(torch.nn.Linear(3, 3))
     ddp.finish_backward()   # world size 1: a no-op
+
+
+def test_flat_buckets_take_gradient_memory_from_the_given_allocator():
+    """``grad_alloc`` is how the direct all-reduce hands out IPC-exportable memory for the gradient buckets: every
+    bucket's gradient must be exactly the tensor the allocator returned, and the parameters' ``.grad`` views of it."""
+    handed_out = []
+
+    def alloc(numel, dtype):
+        t = torch.zeros(numel, dtype=dtype)
+        handed_out.append(t)
+        return t
+
+    m = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    fb = FlatBuckets(m.parameters(), bucket_bytes=64, pad_to=16, grad_alloc=alloc)
+    assert len(handed_out) == len(fb.buckets) >= 2
+    for bk, t in zip(fb.buckets, handed_out):
+        assert bk.flat_grad is t and t.numel() % 16 == 0 and t.numel() == bk.flat_param.numel()
+    m(torch.randn(2, 5)).sum().backward()
+    for bk, t in zip(fb.buckets, handed_out):
+        assert float(t.abs().sum()) > 0
+        for p, o in zip(bk.params, bk.offsets):
+            assert p.grad.data_ptr() == t.data_ptr() + 4 * o
