@@ -590,6 +590,41 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(const ConvA
     }
   }
 
+  // Plain bf16 store with bias, optional same-size residual and none / ReLU - what every layer of the detector body
+  // and the recogniser's trunk asks for - takes a lean path: the general epilogue below decides its modes per value,
+  // several hundred VALU instructions per tile and wave, as many issue cycles as the tile's MFMAs.
+  if (p.out_mode == 0 && !p.y_f32 && p.res_mode <= 1 && (p.act == ACT_NONE || p.act == ACT_RELU) &&
+      (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) {
+    bf16_t* yp = reinterpret_cast<bf16_t*>(p.y);
+    const bool relu = p.act == ACT_RELU;
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      const int n = n0 + wn * TN + i * 16 + fq * 4;
+      if (n >= p.Cout) continue;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        const int lp = wm * TM + j * 16 + frow;
+        const int py = lp / TW, px = lp - py * TW;
+        const int oy = oy0 + py, ox = ox0 + px;
+        if (oy >= p.Ho || ox >= p.Wo) continue;
+        const long long m = ((long long)b * p.Ho + oy) * p.Wo + ox;
+        float v0 = acc[i][j][0] + bv[0], v1 = acc[i][j][1] + bv[1], v2 = acc[i][j][2] + bv[2], v3 = acc[i][j][3] + bv[3];
+        if (p.res_mode == 1) {
+          const u32x2 rr = *reinterpret_cast<const u32x2*>(p.res + m * p.res_cstride + n);
+          v0 += bf16_bits_to_f32(rr[0] & 0xffffu);
+          v1 += bf16_bits_to_f32(rr[0] >> 16);
+          v2 += bf16_bits_to_f32(rr[1] & 0xffffu);
+          v3 += bf16_bits_to_f32(rr[1] >> 16);
+        }
+        if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+        const bf16x4 o = {(bf16_t)v0, (bf16_t)v1, (bf16_t)v2, (bf16_t)v3};
+        *reinterpret_cast<bf16x4*>(yp + m * p.y_cstride + p.y_coff + n) = o;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < FM; ++j) {
     const int lp = wm * TM + j * 16 + frow;
