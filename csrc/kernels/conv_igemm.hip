@@ -68,6 +68,32 @@ template <int FN, int FM>
 __device__ __forceinline__ void conv_epilogue_pixel(const ConvArgs& p, const f32x4 (&acc)[FN][FM], const int j,
                                                     const int m, const int nbase, const int fq,
                                                     const ConvLdsSink sink = ConvLdsSink{nullptr, 0, 0, 0}) {
+  // Plain bf16 store with bias, optional same-size residual and none / ReLU (most layers): decided once per pixel
+  // instead of per value - the general path below costs several hundred VALU instructions per tile and wave.
+  if (p.out_mode == 0 && !p.y_f32 && p.res_mode <= 1 && (p.act == ACT_NONE || p.act == ACT_RELU) &&
+      (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) {
+    const bool relu = p.act == ACT_RELU;
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      const int n = nbase + i * 16 + fq * 4;
+      if (n >= p.Cout) continue;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+      float v0 = acc[i][j][0] + bv[0], v1 = acc[i][j][1] + bv[1], v2 = acc[i][j][2] + bv[2], v3 = acc[i][j][3] + bv[3];
+      if (p.res_mode == 1) {
+        const u32x2 rr = *reinterpret_cast<const u32x2*>(p.res + (long long)m * p.res_cstride + n);
+        v0 += bf16_bits_to_f32(rr[0] & 0xffffu);
+        v1 += bf16_bits_to_f32(rr[0] >> 16);
+        v2 += bf16_bits_to_f32(rr[1] & 0xffffu);
+        v3 += bf16_bits_to_f32(rr[1] >> 16);
+      }
+      if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+      const bf16x4 o = {(bf16_t)v0, (bf16_t)v1, (bf16_t)v2, (bf16_t)v3};
+      if (sink.base) *reinterpret_cast<bf16x4*>(sink.base + (m - sink.m0) * sink.rowb + (n - sink.n0) * 2) = o;
+      else *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.y) + (long long)m * p.y_cstride + p.y_coff + n) = o;
+    }
+    return;
+  }
   const int hw = p.Ho * p.Wo;
   int b = 0, ho = 0, wo = 0;
   if (p.out_mode != 0 || p.res_mode == 2) {
