@@ -734,7 +734,8 @@ __device__ __attribute__((aligned(256))) uint8_t dlamd_zero_page[256];
 // One 4-wave workgroup per CU, one wave per SIMD: the filter (144 registers), a 128 x 32 accumulator (64) and two
 // sets of eight pixel fragments (64) need more than the 256 registers a wave has at two waves per SIMD (the 8 x 16
 // tile form with two workgroups per CU compiles to 62 spilled registers and is not dispatched).
-// Measured on 25 detector pages (bench/conv64_probe.py): 0.240 ms against 0.270 ms for the 256-pixel patch kernel;
+// Measured on 25 detector pages (bench/conv64_probe.py): 0.240 ms against 0.270 ms for the 256-pixel patch kernel
+// with the general epilogue, 0.226 ms for the patch kernel with the same lean epilogue;
 // with one wave per SIMD a tile's phases (DMA issue, MFMAs, epilogue) still run back to back - 7.8 us per tile
 // against 1.9 us of MFMA time.
 template <int TH, int TW>
@@ -1275,8 +1276,8 @@ extern "C" int dlamd_conv2d(const void* x, const void* w, const float* bias, con
   // 8-wave tile halves the weight traffic once more (layer1 0.270 ms, head 0.667).
   if (patch_ok && cfg == 0 && sh == 1 && (Cout <= 64 || (Cout <= 128 && Cin <= 128))) {
     if (Cout <= 64 && (long long)B * a.Ho * a.Wo >= 1000000 && a.Ho >= 16) {
-      // 64 -> 64 on the quarter-scale maps: the resident-filter kernel is 11 % faster alone (0.240 against 0.270 ms
-      // on 25 pages), but it owns its CUs (one wave per SIMD with the whole register file), so in the two-stream
+      // 64 -> 64 on the quarter-scale maps: the resident-filter kernel runs 0.240 ms on 25 pages (patch kernel:
+      // 0.226), and it owns its CUs (one wave per SIMD with the whole register file), so in the two-stream
       // pipeline the other stream's kernels cannot share them: 672 us per call there, bench.py unchanged within
       // noise (961 against 956 pages/s).  Opt-in: DLAMD_CONV_C64=1.
       static const bool c64 = [] { const char* e = getenv("DLAMD_CONV_C64"); return e && e[0] == '1'; }();
