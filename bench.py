@@ -19,10 +19,10 @@ scaling: 100 pages per GPU per step); the timed region is bracketed by a
 barrier + device synchronise on both sides and the per-rank times are
 MAX-reduced.
 
---via-pool measures the product path instead: rank 0 is a front end that drives
-runtime.workers.WorkerPool (one engine process per GPU, dynamic batching, page
-sharding) with N documents in flight per step; the other ranks of a torchrun
-launch only take part in the barriers and never touch a GPU.
+--via-pool measures the product path instead: every rank is a front-end process
+(runtime.workers.WorkerPool) and starts the engine worker server of its own GPU;
+all front ends reach all workers over Unix sockets (least-loaded dispatch,
+shared-memory PDFs, packed results), the layout api/serve.py runs on a node.
 
 The pages are synthetic (rendered text + scanner noise).  No public checkpoint is reachable offline, so the weights are the
 ones this repository trains itself on that page family (train/page_trainer.py,
@@ -84,68 +84,107 @@ def parse_args():
     ap.add_argument("--recognizer", choices=["crnn", "trocr"], default="crnn",
                     help="trocr: TrOCR-base-sized ViT + decoder (random-init, generator line boxes)")
     ap.add_argument("--trocr-tokens", type=int, default=32)
-    ap.add_argument("--in-flight", type=int, default=3, help="--via-pool: documents in flight per GPU (2: 783 - 853 pages/s, 3: 947)")
+    ap.add_argument("--in-flight", type=int, default=3, help="--via-pool: documents in flight per front end (2: 783 - 853 pages/s, 3: 947)")
     ap.add_argument("--via-pool", action="store_true",
-                    help="drive runtime.workers.WorkerPool (the service's multi-GPU back end) from rank 0 instead of one "
-                         "in-process engine per rank")
+                    help="the service's multi-GPU back end: every rank is a front end in front of shared engine worker "
+                         "servers (one per GPU) instead of one in-process engine per rank")
     return ap.parse_args()
 
 
 def main_via_pool(args):
-    """Product path: one front end (rank 0) + one engine worker process per GPU.  A step = N documents of
-    --pages-per-doc pages (weak scaling: one document per GPU per step); like the default mode's back-to-back queue,
-    the documents of all steps are submitted through --in-flight x N client threads (default 3 per GPU), so a
-    worker's engine loop batches pages across them; the pool shards documents over the workers."""
-    import torch.distributed as dist
+    """Product path: N front-end processes in front of N shared engine workers (one per GPU).
+
+    Every rank of the launch is a front end (``runtime.workers.WorkerPool`` over the workers' Unix sockets, the layout
+    ``api/serve.py`` starts on a node) and starts the worker server of its own GPU as a child process; it never
+    touches a GPU itself.  Each front end reaches ALL workers and sends every document to the least-loaded ones.  A
+    step = one document of --pages-per-doc pages per front end (weak scaling); the documents of all steps go
+    through --in-flight client threads per front end, so an engine loop batches pages across documents.  The PDF sits
+    in shared memory (as an upload received by ``api/httpd.py`` does); workers map it."""
+    import subprocess
+    import tempfile
     from concurrent.futures import ThreadPoolExecutor
+
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    n = max(world, args.gpus)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n = world
     if world > 1:
-        dist.init_process_group("gloo")      # CPU tensors only; ranks > 0 never initialise a GPU
+        dist.init_process_group("gloo")      # CPU tensors only: no rank of this mode initialises a GPU
 
     def barrier():
         if world > 1:
             dist.barrier()
 
+    from distributed_llms_amd.api.serve import count_gpus
+    from distributed_llms_amd.pdf import synth
+    from distributed_llms_amd.runtime.extractor import PoolExtractor
+    from distributed_llms_amd.runtime.shm import Segment
+    from distributed_llms_amd.runtime.workers import ShmDocument, WorkerPool
+    from distributed_llms_amd.utils.affinity import allowed_cpus, cpus_for_worker
+
+    use_gpu = not args.cpu and count_gpus() > 0          # counted without bringing the GPU runtime up here
+    size = synth.A4_300DPI if use_gpu else (248, 350)
+    cfg = dict(max_batch_pages=args.batch_pages, use_hip_graphs=not args.no_graphs)
+    if not use_gpu:
+        cfg.update(det_limit_side=160, rec_max_width=256, rec_width_quantum=64)
+    spec = {"model": "full" if use_gpu else "tiny", "cfg": cfg, "weights_dir": args.weights, "recognizer": args.recognizer}
+    sock_dir = os.path.join(tempfile.gettempdir(), "dlamd-bench-%s" % os.environ.get("MASTER_PORT", str(os.getppid())))
+    os.makedirs(sock_dir, exist_ok=True)
+    socks = [os.path.join(sock_dir, f"w{i}.sock") for i in range(n)]
+    try:
+        os.unlink(socks[rank])
+    except OSError:
+        pass
+    cmd = [sys.executable, "-m", "distributed_llms_amd.runtime.worker_server", "--id", str(rank),
+           "--device", f"cuda:{local_rank}" if use_gpu else "cpu", "--socket", socks[rank], "--spec", json.dumps(spec),
+           "--max-wait-ms", "3"]
+    if use_gpu and len(allowed_cpus()) >= 2 * n:
+        cmd += ["--cpus", ",".join(map(str, cpus_for_worker(local_rank, n)))]
+    worker = subprocess.Popen(cmd, cwd=str(ROOT), env=dict(os.environ, PYTHONPATH=str(ROOT)))
+    n_dist = min(args.distinct_pages, args.pages_per_doc)
+    rendered = [synth.render_page(1000 * rank + i, size=size, font_px=42 if use_gpu else 10, margin=220 if use_gpu else 16)
+                for i in range(n_dist)]
+    enc_d = [synth.encode_page_jpeg(rendered[i][0], restart_blocks=args.restart_blocks) for i in range(n_dist)]
+    pdf = synth.make_scanned_pdf([rendered[i % n_dist][0] for i in range(args.pages_per_doc)], codec="jpeg",
+                                 encoded=[enc_d[i % n_dist] for i in range(args.pages_per_doc)])
+    seg = Segment.create(len(pdf))
+    seg.buf[: len(pdf)] = pdf
+    doc = ShmDocument(seg, 0, len(pdf))
     out = None
-    if rank == 0:
-        from distributed_llms_amd.api.serve import count_gpus
-        from distributed_llms_amd.pdf import synth
-        from distributed_llms_amd.runtime.extractor import PoolExtractor
-        from distributed_llms_amd.runtime.workers import WorkerPool
-
-        use_gpu = not args.cpu and count_gpus() > 0          # counted without bringing the GPU runtime up here
-        size = synth.A4_300DPI if use_gpu else (248, 350)
-        cfg = dict(max_batch_pages=args.batch_pages, use_hip_graphs=not args.no_graphs)
-        if not use_gpu:
-            cfg.update(det_limit_side=160, rec_max_width=256, rec_width_quantum=64)
-        spec = {"model": "full" if use_gpu else "tiny", "cfg": cfg, "weights_dir": args.weights, "recognizer": args.recognizer}
-        devices = [f"cuda:{i}" for i in range(n)] if use_gpu else ["cpu"] * n
-        n_dist = min(args.distinct_pages, args.pages_per_doc)
-        rendered = [synth.render_page(i, size=size, font_px=42 if use_gpu else 10, margin=220 if use_gpu else 16)
-                    for i in range(n_dist)]
-        enc_d = [synth.encode_page_jpeg(rendered[i][0], restart_blocks=args.restart_blocks) for i in range(n_dist)]
-        pdf = synth.make_scanned_pdf([rendered[i % n_dist][0] for i in range(args.pages_per_doc)], codec="jpeg",
-                                     encoded=[enc_d[i % n_dist] for i in range(args.pages_per_doc)])
-        pool = WorkerPool(devices, spec, max_wait_ms=3.0).start()
+    pool = None
+    try:
+        t_end = time.time() + 600
+        while not all(os.path.exists(s_) for s_ in socks):
+            if worker.poll() is not None or time.time() > t_end:
+                raise RuntimeError("the engine worker of rank %d did not come up" % rank)
+            time.sleep(0.2)
+        pool = WorkerPool(["unix:" + s_ for s_ in socks], home=rank, min_pages_per_shard=args.pages_per_doc).start(600.0)
         ext = PoolExtractor(pool)
-        try:
-            with ThreadPoolExecutor(max_workers=args.in_flight * n) as tp:
-                def run(tag, steps):
-                    docs = list(tp.map(lambda k: ext.extract_document(pdf, f"{tag}-{k}"), range(n * steps)))
-                    assert all(len(d.pages) == args.pages_per_doc for d in docs)
-                    return sum(len(p.lines) for d in docs for p in d.pages)
+        with ThreadPoolExecutor(max_workers=args.in_flight) as tp:
+            def run(tag, steps):
+                docs = list(tp.map(lambda k: ext.extract_document(doc, f"{tag}-{rank}-{k}"), range(steps)))
+                assert all(len(d.pages) == args.pages_per_doc for d in docs)
+                return sum(d.pages.n_lines for d in docs)
 
-                if args.warmup:
-                    run("warm", args.warmup)
-                barrier()
-                t0 = time.perf_counter()
-                n_lines = run("bench", args.steps)
-                dt = time.perf_counter() - t0
-                barrier()
-            total_pages = args.steps * args.pages_per_doc * n
+            if args.warmup:
+                run("warm", args.warmup)
+            barrier()
+            c0 = time.process_time()
+            t0 = time.perf_counter()
+            n_lines = run("bench", args.steps)
+            dt = time.perf_counter() - t0
+            cpu = time.process_time() - c0
+            barrier()
+        if world > 1:
+            t = torch.tensor([dt, cpu, float(n_lines)], dtype=torch.float64)
+            tmax = t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            dt, cpu, n_lines = float(tmax[0]), float(t[1]) / world, int(t[2])
+        total_pages = args.steps * args.pages_per_doc * n
+        if rank == 0:
             out = {
                 "metric": "pages/sec (whole node) on 300-DPI A4 scans", "value": round(total_pages / dt, 3), "unit": "pages/s",
                 "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
@@ -156,15 +195,22 @@ def main_via_pool(args):
                 "config": {"model": "DBNet-R18 + CRNN + CTC greedy", "global_batch": args.pages_per_doc * n,
                            "seq_len": 640 if use_gpu else 64, "parallelism": f"pool{n}",
                            "pages_per_step_per_gpu": args.pages_per_doc, "page_px": list(size),
-                           "documents": f"{args.in_flight * n} in flight through WorkerPool (front end + one engine process per GPU, "
-                                        "dynamic batching, page sharding)",
-                           "lines_recognized": n_lines, "pool": {k: v for k, v in pool.describe().items() if k != "worker_stats"}},
+                           "documents": f"{args.in_flight} in flight per front end; {n} front-end process(es) in front of {n} "
+                                        "shared engine worker(s) (Unix sockets, shared-memory PDFs, packed results)",
+                           "lines_recognized": n_lines,
+                           "front_end_cpu_s_per_100_pages": round(100.0 * cpu / (args.steps * args.pages_per_doc), 4),
+                           "pool": {k: v for k, v in pool.describe().items() if k != "worker_stats"}},
             }
-        finally:
+    finally:
+        if pool is not None:
             pool.stop()
-    else:
-        barrier()
-        barrier()
+        barrier()                      # nobody's worker goes away while another front end still uses it
+        worker.terminate()
+        try:
+            worker.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            worker.kill()
+        seg.release()
     if out is not None:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -278,6 +324,7 @@ def main():
     engine.timer = type(engine.timer)()
     pipe.timer = type(pipe.timer)()
     sync()
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     n_lines = 0
     if stream_docs:
@@ -292,10 +339,11 @@ def main():
             n_lines += sum(len(p.lines) for p in doc.pages)
     sync()
     dt = time.perf_counter() - t0
+    host_cpu = time.process_time() - cpu0        # every thread of this rank: engine thread, decode pool, result strings
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt, host_cpu], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, host_cpu = float(t[0].item()), float(t[1].item())
 
     cer = None
     if trained and rank == 0:   # accuracy of the timed output (outside the timed region)
@@ -345,6 +393,7 @@ def main():
                 "p50_extract_latency_ms": round(1000.0 * (sorted(lat)[len(lat) // 2] if lat else dt / args.steps), 1),
                 "documents": "queued back to back through one engine pipeline" if stream_docs else "one at a time",
                 "lines_recognized": n_lines,
+                "host_cpu_s_per_100_pages": round(100.0 * host_cpu / (args.steps * args.pages_per_doc), 4),
                 "weights": "trained (weights/)" if trained else "random-init",
                 "cer_vs_truth": None if cer is None else round(cer, 5),
                 "baseline": "CPU proxy: same graphs, torch CPU eager, ProcessPoolExecutor(8) on 8 vCPU = 0.84 pages/s "

@@ -6,6 +6,10 @@
 //                           optionally appends the new K/V row at a device-side step counter, so a
 //                           whole greedy-decode step has static launch parameters (hipGraph replay)
 //   embed_rows_kernel       token + learned position embedding gather for the decoder
+//   decode_bookkeep_kernel  tail of a greedy-decode step: record the step's token for every live sequence, sum
+//                           its probability, mark sequences that emitted EOS, advance the step counter and
+//                           publish "every sequence is done" - all of it inside the captured step, so the host
+//                           loop around the graph replays launches nothing else
 // Head dimension is 64 (768/12 for the encoder, 1024/16 for the decoder).
 //
 // attention_fwd orientation (per wave: 16 queries, per block: 4 waves = 64 queries):
@@ -365,5 +369,49 @@ extern "C" int dlamd_embed_rows(const void* ids, const void* tok, const void* po
   if (B > 0x7fffffffLL || C <= 0 || V <= 0 || P <= 0) return -1;
   hipLaunchKernelGGL(embed_rows_kernel, dim3((unsigned)B), dim3(256), 0, stream, (const int*)ids, (const bf16_t*)tok,
                      (const bf16_t*)pos, (const int*)t_ptr, (bf16_t*)y, B, C, V, P, t_const, emb_scale);
+  return DLAMD_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------ greedy-decode bookkeeping
+// One workgroup.  tokens / probs: this step's argmax per sequence [B].  out: [max_len, B] token history (pre-filled
+// with the pad id), psum / cnt: running probability sum and token count per sequence, done: 1 once a sequence has
+// emitted eos (rows >= B_live are marked done by the caller).  t_ptr: device step counter, read as this step's index
+// and incremented here.  flag: int32 in host-visible memory; set to (step + 1) the first time no sequence is live.
+__global__ __launch_bounds__(256) void decode_bookkeep_kernel(const int* __restrict__ tokens, const float* __restrict__ probs,
+                                                              int* __restrict__ t_ptr, int* __restrict__ out,
+                                                              float* __restrict__ psum, float* __restrict__ cnt,
+                                                              unsigned char* __restrict__ done, int* __restrict__ flag,
+                                                              int B, int max_len, int eos) {
+  __shared__ int s_live[4];
+  const int t = *t_ptr;
+  int live = 0;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    if (!done[b]) {
+      const int tok = tokens[b];
+      if (t < max_len) {
+        out[(long long)t * B + b] = tok;
+        psum[b] += probs[b];
+        cnt[b] += 1.f;
+      }
+      if (tok == eos) done[b] = 1;
+      else ++live;
+    }
+  }
+  live = (int)wave_reduce_sum((float)live);
+  if ((threadIdx.x & 63) == 0) s_live[threadIdx.x >> 6] = live;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *t_ptr = t + 1;
+    if (s_live[0] + s_live[1] + s_live[2] + s_live[3] == 0 && *flag == 0) *flag = t + 1;
+  }
+}
+
+extern "C" int dlamd_decode_bookkeep(const void* tokens, const void* probs, void* t_ptr, void* out, void* psum, void* cnt,
+                                     void* done, void* flag, int B, int max_len, int eos, hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (!tokens || !probs || !t_ptr || !out || !psum || !cnt || !done || !flag || max_len <= 0) return -1;
+  if (B > (1 << 22)) return -2;       // the live count goes through a float reduction
+  hipLaunchKernelGGL(decode_bookkeep_kernel, dim3(1), dim3(256), 0, stream, (const int*)tokens, (const float*)probs,
+                     (int*)t_ptr, (int*)out, (float*)psum, (float*)cnt, (unsigned char*)done, (int*)flag, B, max_len, eos);
   return DLAMD_CHECK_LAUNCH();
 }

@@ -44,6 +44,9 @@ from .multipart import MultipartError, StreamingForm, UploadTooLarge, parse_mult
 logger = logging.getLogger("distributed_llms_amd")
 
 MAX_UPLOAD_BYTES = int(os.environ.get("OCR_MAX_UPLOAD_BYTES", str(2 << 30)))
+# upload bytes that may be in flight in one front-end process at a time (announced lengths of the requests being
+# received): beyond it new uploads are answered 503 instead of each pinning a buffer of its announced size
+MAX_INFLIGHT_UPLOAD_BYTES = int(os.environ.get("OCR_MAX_INFLIGHT_UPLOAD_BYTES", str(16 << 30)))
 
 
 def make_stores(settings: Settings):
@@ -164,6 +167,7 @@ def create_app(settings: Optional[Settings] = None, status: Optional[StatusStore
             pass
         if state.get("own_extractor") and state.get("extractor") is not None:
             state["extractor"].close()
+        seg_pool.clear()
         logger.info("Services shut down")
 
     app = FastAPI(title="PDF OCR Service", description="MI355X-native PDF text extraction / OCR service",
@@ -182,16 +186,45 @@ def create_app(settings: Optional[Settings] = None, status: Optional[StatusStore
     app.add_middleware(PollingFastPath, ctx=state, count=_count)
 
     # ------------------------------------------------------------------ POST /extract
+    inflight = {"bytes": 0}
+    from ..runtime.shm import SegmentPool
+
+    # finished uploads' segments are kept for the next upload of that size (their pages are already faulted in)
+    seg_pool = SegmentPool(int(os.environ.get("OCR_SHM_POOL_BYTES", str(2 << 30))))
+
     @app.post("/extract")
     async def upload_pdf(request: Request):
+        seg = None                 # shared-memory segment the upload is received into (GPU worker pool back ends)
+        handed_over = False
+        announced = 0
         try:
             clen = request.headers.get("content-length")
+            jobs: JobManager = request.app.state.ctx["jobs"]
             try:
                 # the body is consumed as it arrives: the cap holds for chunked uploads too, and the file's SHA-256
                 # is computed on a helper thread while the rest of the upload is still on the wire
+                factory = None
+                if getattr(jobs.extractor, "wants_shm", False):
+                    # the workers map the upload instead of receiving a copy: it is received INTO the segment
+                    def factory(n):
+                        nonlocal seg
+                        seg = seg_pool.acquire(n)
+                        return seg.buf
+
+                announced = int(clen) if clen and clen.isdigit() else 0
+                if inflight["bytes"] + announced > MAX_INFLIGHT_UPLOAD_BYTES and inflight["bytes"] > 0:
+                    announced = 0
+                    _count("extract", 503)
+                    return JSONResponse({"detail": "too many uploads in flight, retry shortly"}, status_code=503,
+                                        headers={"retry-after": "1"})
+                inflight["bytes"] += announced
                 form = StreamingForm(request.headers.get("content-type"), MAX_UPLOAD_BYTES,
                                      int(clen) if clen and clen.isdigit() else None,
-                                     hash_pool=request.app.state.ctx["jobs"].hash_pool)
+                                     hash_pool=jobs.hash_pool, buffer_factory=factory)
+                sink = (request.scope.get("extensions") or {}).get("dlamd.body_sink")
+                if sink is not None and form.fixed and form.content_length:
+                    # api/httpd.py: the socket's bytes are written to the form's buffer by the kernel itself
+                    sink["set"](form.buffer())
                 async for chunk in request.stream():
                     form.feed(chunk)
                 parts = form.finish(defer_hash=True)
@@ -227,18 +260,29 @@ def create_app(settings: Optional[Settings] = None, status: Optional[StatusStore
             else:
                 hash_fut = None
                 document_hash = form.sha256_hex() or hashlib.sha256(file_bytes).hexdigest()
-            jobs: JobManager = request.app.state.ctx["jobs"]
             existing = await jobs.claim(document_id, document_hash, file_part.filename or "")
             if existing is not None:
                 _count("extract", 200)
                 return {"status": existing.get("status", "unknown")}
-            jobs.start(file_bytes, document_id, document_hash, hash_future=hash_fut)
+            payload = file_bytes
+            if seg is not None and file_part.offset >= 0:
+                from ..runtime.workers import ShmDocument
+
+                del file_bytes, parts                   # views of the mapping: the job's owner unmaps it when done
+                payload = ShmDocument(seg, file_part.offset, len(file_part.data), seg_pool)
+                file_part = None
+                handed_over = True
+            jobs.start(payload, document_id, document_hash, hash_future=hash_fut)
             _count("extract", 200)
             return {"status": "ok"}
         except Exception as e:  # noqa: BLE001
             logger.error(f"Error handling PDF upload: {str(e)}")
             _count("extract", 500)
             return JSONResponse({"detail": f"Error processing PDF: {str(e)}"}, status_code=500)
+        finally:
+            inflight["bytes"] -= announced
+            if seg is not None and not handed_over:
+                seg.release()
 
     # ------------------------------------------------------------------ GET /check-status/{id}
     @app.get("/check-status/{document_id}")

@@ -12,7 +12,16 @@ polling ``/check-status`` every 10 ms for each of 32 documents in flight keeps o
 * keep-alive, ``Content-Length`` and chunked request bodies, ``Expect: 100-continue``, chunked responses when the
   application streams without a length, pipelined requests served in order, read back-pressure, idle timeout;
 * the ASGI lifespan protocol, and a listening socket passed in as a file descriptor (``api/serve.py`` binds one
-  port for several front-end processes).
+  port for several front-end processes);
+* ``scope["extensions"]["dlamd.body_sink"]``: an application that knows where the body has to end up (``POST
+  /extract`` receives a scan into a shared-memory segment the GPU workers map) hands that buffer over with
+  ``sink["set"](buffer)``; from then on the kernel copies the socket's bytes straight to ``buffer[body offset:]`` and
+  ``receive()`` delivers memoryview slices OF that buffer - the upload is written exactly once on its way from the
+  network card to the PDF parser;
+* request framing is strict where leniency is dangerous behind a proxy: ``Content-Length`` together with
+  ``Transfer-Encoding``, repeated or differing ``Content-Length``, a transfer coding other than exactly ``chunked``
+  and chunk sizes that are not plain hex digits are all answered 400, and bytes pipelined behind a request that is
+  still being served are bounded (431) instead of buffered without limit.
 
 Not supported (answered with an error or by closing): HTTP/2, WebSocket upgrades, TLS (terminate it in front, as the
 reference's load balancer does, terraform/main.tf:176-230).  ``python -m distributed_llms_amd.api.serve --server
@@ -34,6 +43,8 @@ CHUNK = 1 << 20                 # body chunk buffer
 MAX_HEADER = 64 << 10
 MAX_QUEUED = 8                  # body chunks waiting for the application before reading pauses
 KEEPALIVE_S = 5.0
+MAX_PIPELINED = MAX_HEADER      # bytes that may wait in the header buffer while a response is still being produced
+_HEX = frozenset(b"0123456789abcdefABCDEF")
 _REASONS = {200: b"OK", 201: b"Created", 204: b"No Content", 304: b"Not Modified", 400: b"Bad Request",
             404: b"Not Found", 405: b"Method Not Allowed", 413: b"Payload Too Large", 422: b"Unprocessable Entity",
             431: b"Request Header Fields Too Large", 500: b"Internal Server Error", 503: b"Service Unavailable",
@@ -73,7 +84,7 @@ def parse_head(head: bytes) -> Tuple[bytes, bytes, bytes, List[Tuple[bytes, byte
 
 
 class _Request:
-    __slots__ = ("scope", "remaining", "chunked", "expect", "keep_alive", "chunk_state", "body_done")
+    __slots__ = ("scope", "remaining", "chunked", "expect", "keep_alive", "chunk_state", "body_done", "body_pos", "sink")
 
 
 class HttpProtocol(asyncio.BufferedProtocol):
@@ -97,6 +108,7 @@ class HttpProtocol(asyncio.BufferedProtocol):
         self.write_ok.set()
         self._ended = False
         self._head: Optional[bytes] = None
+        self._sink_head = self._sink_tail = 0          # body offsets of the last in-place piece queued for receive()
 
     # ------------------------------------------------------------------ transport callbacks
     def connection_made(self, transport):
@@ -132,20 +144,50 @@ class HttpProtocol(asyncio.BufferedProtocol):
     def get_buffer(self, sizehint):
         r = self.req
         if r is not None and not r.chunked and r.remaining > 0 and self.hlen == 0:
+            if r.sink is not None and self.cur is None:
+                # the application named the body's destination: the kernel writes there
+                return r.sink[r.body_pos : r.body_pos + r.remaining]
             # fixed-length body: the kernel writes into the chunk that the application will receive
             if self.cur is None:
                 self.cur = bytearray(min(CHUNK, r.remaining))
                 self.cur_len = 0
             return memoryview(self.cur)[self.cur_len:]
-        if self.hlen >= len(self.hbuf):
-            self.hbuf.extend(bytes(4096))
+        if self.hlen >= min(len(self.hbuf), MAX_PIPELINED + 1):
+            if (r is None or r.body_done) and self.task is not None and not self.task.done() and self.hlen > MAX_PIPELINED:
+                # a client that keeps sending while its previous request is still being answered: stop reading until
+                # the response is out (_run resumes), never grow the buffer without bound
+                if not self.paused:
+                    self.paused = True
+                    self.transport.pause_reading()
+            if self.hlen >= len(self.hbuf):
+                self.hbuf.extend(bytes(4096))
         return memoryview(self.hbuf)[self.hlen:]
 
     def buffer_updated(self, n):
         r = self.req
         if r is not None and not r.chunked and r.remaining > 0 and self.hlen == 0:
+            if r.sink is not None and self.cur is None:
+                piece = r.sink[r.body_pos : r.body_pos + n]
+                r.body_pos += n
+                r.remaining -= n
+                q = self.queue
+                if q and isinstance(q[-1], memoryview) and q[-1].obj is r.sink.obj and self._sink_tail == r.body_pos - n:
+                    # the application has not taken the previous in-place piece yet: one longer piece, not two
+                    a = self._sink_head
+                    q[-1] = r.sink[a : r.body_pos]
+                    self._sink_tail = r.body_pos
+                    if self.waiter is not None and not self.waiter.done():
+                        self.waiter.set_result(None)
+                else:
+                    self._sink_head, self._sink_tail = r.body_pos - n, r.body_pos
+                    self._push(piece)
+                if r.remaining == 0:
+                    r.body_done = True
+                    self._push(None)
+                return
             self.cur_len += n
             r.remaining -= n
+            r.body_pos += n
             if self.cur_len == len(self.cur) or r.remaining == 0:
                 self._push(memoryview(self.cur)[: self.cur_len])
                 self.cur = None
@@ -171,6 +213,8 @@ class HttpProtocol(asyncio.BufferedProtocol):
             r = self.req
             if r is None:
                 if self.task is not None and not self.task.done():
+                    if self.hlen > MAX_PIPELINED + MAX_HEADER:
+                        self._reject(431, "too many pipelined bytes")
                     return                      # previous response still being produced: leave the bytes queued
                 end = self.hbuf.find(b"\r\n\r\n", 0, self.hlen)
                 if end < 0:
@@ -197,6 +241,7 @@ class HttpProtocol(asyncio.BufferedProtocol):
                 self._push(bytes(self.hbuf[:take]))
                 self._drop(take)
                 r.remaining -= take
+                r.body_pos += take
             if r.remaining == 0:
                 r.body_done = True
                 self._push(None)
@@ -218,11 +263,12 @@ class HttpProtocol(asyncio.BufferedProtocol):
                 if self.hlen > 4096:
                     self._reject(400, "chunk size line too long")
                 return False
-            try:
-                size = int(bytes(self.hbuf[:eol]).split(b";")[0].strip(), 16)
-            except ValueError:
+            digits = bytes(self.hbuf[:eol]).split(b";")[0].strip(b" \t")
+            # plain hex only: int(x, 16) would also take '-1', '+5', '0x10' and '1_0'
+            if not 1 <= len(digits) <= 16 or not _HEX.issuperset(digits):
                 self._reject(400, "bad chunk size")
                 return False
+            size = int(digits, 16)
             self._drop(eol + 2)
             st[0], st[1] = ("data", size) if size else ("trailer", 0)
             return True
@@ -262,19 +308,33 @@ class HttpProtocol(asyncio.BufferedProtocol):
         chunked = False
         expect = False
         conn = b""
+        te = None
         for k, v in headers:
             if k == b"content-length":
-                if not v.isdigit():
+                if not v.isdigit() or len(v) > 18:
                     raise _BadRequest(400, "bad content-length")
+                if clen is not None:
+                    # two Content-Length fields (equal or not): a proxy in front may have framed by the other one
+                    raise _BadRequest(400, "repeated content-length")
                 clen = int(v)
             elif k == b"transfer-encoding":
-                chunked = v.lower().endswith(b"chunked")
+                if te is not None:
+                    raise _BadRequest(400, "repeated transfer-encoding")
+                te = v.lower()
             elif k == b"expect":
                 expect = v.lower() == b"100-continue"
             elif k == b"connection":
                 conn = v.lower()
             elif k == b"upgrade" and v.lower() == b"websocket":
                 raise _BadRequest(400, "websocket upgrades are not served")
+        if te is not None:
+            if te != b"chunked":
+                # 'gzip, chunked' needs a decoder this server does not have; 'xchunked' or 'chunked, identity' must not
+                # be read as chunked framing
+                raise _BadRequest(400, "unsupported transfer-encoding")
+            if clen is not None:
+                raise _BadRequest(400, "content-length together with transfer-encoding")
+            chunked = True
         r = _Request()
         r.keep_alive = (version == b"HTTP/1.1" and b"close" not in conn) or (version == b"HTTP/1.0" and b"keep-alive" in conn)
         r.chunked = chunked
@@ -282,12 +342,18 @@ class HttpProtocol(asyncio.BufferedProtocol):
         r.expect = expect
         r.chunk_state = ["size", 0]
         r.body_done = not chunked and r.remaining == 0
+        r.body_pos = 0
+        r.sink = None
+        ext = {}
+        if not chunked and r.remaining > 0:
+            ext["dlamd.body_sink"] = {"set": lambda buf, r=r: self._set_sink(r, buf), "length": r.remaining}
         r.scope = {
             "type": "http", "asgi": {"version": "3.0", "spec_version": "2.3"}, "http_version": version[5:].decode(),
             "method": method.decode().upper(), "scheme": "http", "path": unquote_to_bytes(path).decode("utf-8", "replace"),
             "raw_path": path, "query_string": query, "root_path": "", "headers": headers,
             "client": tuple(self.client[:2]) if self.client else None,
             "server": tuple(self.sockname[:2]) if self.sockname else None, "state": self.server.state.copy(),
+            "extensions": ext,
         }
         self.req = r
         self.queue = []
@@ -298,6 +364,22 @@ class HttpProtocol(asyncio.BufferedProtocol):
             self.idle.cancel()
             self.idle = None
         self.task = self.loop.create_task(self._run(r))
+
+    def _set_sink(self, r: _Request, buf) -> bool:
+        """The application's destination for the rest of this request's body: ``buf[k]`` is body byte ``k``.  Returns
+        False when it cannot be used (wrong request, too small, not writable)."""
+        if r is not self.req or r.chunked or r.sink is not None:
+            return False
+        mv = memoryview(buf)
+        if mv.readonly or mv.ndim != 1 or mv.itemsize != 1 or len(mv) < r.body_pos + r.remaining:
+            return False
+        if self.cur is not None:
+            # a chunk is half filled: hand over what it holds, the sink takes over from the next byte
+            if self.cur_len:
+                self._push(memoryview(self.cur)[: self.cur_len])
+            self.cur = None
+        r.sink = mv
+        return True
 
     def _reject(self, code: int, msg: str):
         body = msg.encode()

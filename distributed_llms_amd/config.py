@@ -145,6 +145,10 @@ class Settings:
     node_id: str = field(default_factory=lambda: os.uname().nodename)
     fault_inject: str = ""
     force_pool: bool = False         # use the worker-process pool even with a single GPU
+    worker_sockets: Optional[str] = None   # "path,path,...": Unix sockets of the node's shared worker servers (api/serve.py)
+    home_worker: int = 0             # index into worker_sockets of the worker next to this front end (breaks load ties)
+    engine_model: str = "full"       # full | stub (no model, no GPU: front-end capacity tests, bench/frontend_ceiling.py)
+    stub_pages_per_s: float = 1000.0
     cpu_model: str = "full"          # CPU oracle path model size: full | tiny (tests)
 
     @classmethod
@@ -179,6 +183,10 @@ class Settings:
             use_hip_graphs=_get_bool(e, "OCR_USE_HIP_GRAPHS", True),
             fault_inject=e.get("FAULT_INJECT", ""),
             force_pool=_get_bool(e, "OCR_FORCE_POOL", False),
+            worker_sockets=e.get("OCR_WORKER_SOCKETS") or None,
+            home_worker=_get_int(e, "OCR_HOME_WORKER", 0),
+            engine_model=e.get("OCR_ENGINE_MODEL", "full"),
+            stub_pages_per_s=_get_float(e, "OCR_STUB_PAGES_PER_S", 1000.0),
             cpu_model=e.get("OCR_CPU_MODEL", "full"),
             **({"node_id": e["OCR_NODE_ID"]} if e.get("OCR_NODE_ID") else {}),
         )

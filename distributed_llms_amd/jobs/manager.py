@@ -86,6 +86,8 @@ class JobManager:
     async def process(self, pdf_bytes: bytes, document_id: str, document_hash: Optional[str] = None,
                       hash_future=None) -> Dict[str, str]:
         t0 = time.perf_counter()
+        fut = None
+        ok = False
         try:
             loop = asyncio.get_running_loop()
             # extraction does not read the digest: it starts first, and a digest still on its way (the hash thread
@@ -95,7 +97,9 @@ class JobManager:
                 try:
                     document_hash = await asyncio.wrap_future(hash_future)
                 except Exception:  # noqa: BLE001 - the streamed digest is an optimisation, never a reason to fail
-                    document_hash = await self._io(lambda: hashlib.sha256(pdf_bytes).hexdigest())
+                    raw = pdf_bytes.view() if hasattr(pdf_bytes, "view") else pdf_bytes
+                    document_hash = await self._io(lambda: hashlib.sha256(raw).hexdigest())
+                    del raw
             await self._io(self.status.update, document_id, {
                 "status": "processing", "document_hash": document_hash, "started_at": _now(), "owner": self.node_id})
             try:
@@ -114,6 +118,7 @@ class JobManager:
                 metrics.STAGE_SECONDS.labels("store").observe(time.perf_counter() - t1)
                 metrics.DOCUMENTS.labels("completed").inc()
                 metrics.PAGES.inc(int(result.get("pages", 0) or 0))
+                ok = True
                 return {"status": "completed", "result": result["result"]}
             await self._fail(document_id, document_hash, result["error"])
             return {"status": "failed", "error": result["error"]}
@@ -124,6 +129,14 @@ class JobManager:
         finally:
             metrics.STAGE_SECONDS.labels("total").observe(time.perf_counter() - t0)
             metrics.JOBS_IN_FLIGHT.set(max(0, len(self.tasks) - 1))
+            if hasattr(pdf_bytes, "release"):
+                # an upload that was received into shared memory (api/app.py): this job owns the segment.  After a
+                # deadline the extract thread may still be parsing it - the name goes now, the mapping when that
+                # thread lets go of its views
+                if fut is not None and not fut.done():
+                    fut.add_done_callback(lambda _f, d=pdf_bytes: d.release())
+                else:
+                    pdf_bytes.release(reusable=ok)
 
     async def _fail(self, document_id: str, document_hash: Optional[str], error: str) -> None:
         await self._io(self.status.update, document_id, {

@@ -12,10 +12,14 @@ MI355X inference path (``encode`` / ``generate``):
   Q, K, V are one fused [3d, d] GEMM, cross-attention K/V for all 577 memory tokens one [2d, d_enc] GEMM
   per layer, computed once per batch;
 * encoder attention = flash-style MFMA kernel streaming K/V through LDS in 64-key blocks;
-* one greedy decode step (embed -> 12 layers -> LM-head GEMM -> argmax -> step counter) has fully static
-  launch parameters: the step index lives in device memory and the decode-attention kernel appends to the
-  KV cache itself, so the whole step (~140 launches) is captured ONCE per batch bucket in a hipGraph and
-  replayed per generated token.  Decode is GEMV-shaped at small batch, so crops are batched (>= 256).
+* one greedy decode step (embed -> 12 layers -> LM-head GEMM -> argmax -> token history / EOS marks / step
+  counter) has fully static launch parameters: the step index lives in device memory and the decode-attention
+  kernel appends to the KV cache itself, so the whole step (~140 launches) is captured ONCE per batch bucket in
+  a hipGraph and replayed per generated token; the host loop around the replays launches nothing else and learns
+  that every sequence has finished from a flag in pinned host memory, read without synchronising the stream.
+  Decode is GEMV-shaped at small batch, so crops are batched (>= 256);
+* the encoder runs in chunks of ``ENC_CHUNK`` crops: its activations then stay inside the 256 MB last-level cache
+  (a 1024-crop pass measured 4490 crops/s in one piece against 6080 at 256).
 
 ``forward_reference`` is the plain PyTorch fp32 implementation over the same parameters (test oracle).
 In the reference service this role is played by magic-pdf's UniMERNet / OCR recognizers on CPU
@@ -284,25 +288,26 @@ class TrOCR(nn.Module):
         if pk["dec_ln"] is not None:
             x = T.layernorm(x, *pk["dec_ln"])
         logits = linear_bf16(x, *pk["lm"])
-        idx, prob = ctc_ops.row_argmax(logits)
-        st.tokens.copy_(idx)
-        st.probs.copy_(prob)
-        st.t.add_(1)
+        ctc_ops.row_argmax(logits, out=(st.tokens, st.probs))
+        # history, probability sums, EOS marks, step counter and the all-done flag: one small kernel inside the step
+        T.decode_bookkeep(st.tokens, st.probs, st.t, st.out, st.psum, st.cnt, st.done, st.flag, cfg.eos)
+
+    ENC_CHUNK = 256
 
     @torch.no_grad()
     def generate(self, x: torch.Tensor, max_len: Optional[int] = None, use_graph: bool = True,
                  eos_check_every: int = 8) -> Tuple[torch.Tensor, torch.Tensor]:
         """x: [B, S, S, 8] bf16 -> (tokens [B, max_len] int32, mean token probability [B]).
 
-        Decoding stops as soon as every sequence of the batch has produced ``eos`` (looked at every
-        ``eos_check_every`` steps, one small device-to-host read each); positions after a sequence's ``eos`` are
-        filled with ``pad`` and do not count towards its mean probability.  0 disables the early exit."""
+        Decoding stops once every sequence of the batch has produced ``eos``: the step itself raises a flag in pinned
+        host memory, and every ``eos_check_every`` steps the host waits for the step it launched that many steps ago
+        (never for the newest one - the queue stays filled) and looks at the flag.  Positions after a sequence's
+        ``eos`` are filled with ``pad`` and do not count towards its mean probability.  0 disables the early exit."""
         if self._pk is None:
             self.prepare()
         cfg, pk = self.cfg, self._pk
         max_len = min(max_len or cfg.max_len, cfg.max_len)
         B = x.shape[0]
-        mem = self.encode(x)
         on_gpu = x.is_cuda
         Bb = B if not on_gpu else max(16, 1 << (B - 1).bit_length())
         g = self._graphs.get(Bb)
@@ -310,29 +315,33 @@ class TrOCR(nn.Module):
             g = _DecodeGraph(self, Bb, capture=on_gpu and use_graph)
             self._graphs[Bb] = g
         st = g.state
-        # cross-attention K/V of every layer, once per batch
-        for li, l in enumerate(pk["dec"]):
-            kv = linear_bf16(mem, *l["xkv"])
-            st.k_cross[li][:B].copy_(kv[..., : cfg.dec_dim])
-            st.v_cross[li][:B].copy_(kv[..., cfg.dec_dim :])
-        st.tokens.fill_(cfg.bos)
-        st.t.zero_()
-        out = torch.full((max_len, Bb), cfg.pad, dtype=torch.int32, device=x.device)
-        psum = torch.zeros((Bb,), dtype=torch.float32, device=x.device)
-        cnt = torch.zeros((Bb,), dtype=torch.float32, device=x.device)
-        done = torch.zeros((Bb,), dtype=torch.bool, device=x.device)
-        done[B:] = True                                     # padding rows of the batch bucket
+        # encoder and the cross-attention K/V of every layer, once per batch, a chunk of crops at a time
+        for c0 in range(0, B, self.ENC_CHUNK):
+            mem = self.encode(x[c0 : c0 + self.ENC_CHUNK])
+            for li, l in enumerate(pk["dec"]):
+                kv = linear_bf16(mem, *l["xkv"])
+                st.k_cross[li][c0 : c0 + mem.shape[0]].copy_(kv[..., : cfg.dec_dim])
+                st.v_cross[li][c0 : c0 + mem.shape[0]].copy_(kv[..., cfg.dec_dim :])
+        st.reset(B, cfg)
+        events = []
+        steps = 0
         for s in range(max_len):
             g.step()
-            live = ~done
-            out[s] = torch.where(live, st.tokens, out[s])
-            psum += st.probs * live
-            cnt += live
-            done |= st.tokens == cfg.eos
-            if eos_check_every > 0 and (s + 1) % eos_check_every == 0 and s + 1 < max_len and bool(done.all()):
+            steps = s + 1
+            if eos_check_every > 0 and on_gpu:
+                ev = torch.cuda.Event()
+                ev.record()
+                events.append(ev)
+                if steps % eos_check_every == 0 and steps < max_len:
+                    if len(events) > eos_check_every:
+                        events[-1 - eos_check_every].synchronize()       # an OLD step: the newer ones keep the GPU busy
+                    if int(st.flag[0]) != 0:
+                        break
+            elif eos_check_every > 0 and int(st.flag[0]) != 0:
                 break
-        self.last_decode_steps = s + 1
-        return out[:, :B].t().contiguous(), (psum[:B] / cnt[:B].clamp(min=1.0))
+        self.last_decode_steps = steps
+        out = st.out[:max_len, :B].t().contiguous()
+        return out, (st.psum[:B] / st.cnt[:B].clamp(min=1.0))
 
     def tokens_to_text(self, tokens: torch.Tensor, vocab=None) -> List[str]:
         """ids -> text through the native byte-level vocabulary (csrc/runtime/bpe_tokenizer.cpp).  Without a
@@ -366,6 +375,27 @@ class _DecodeState:
         self.v_self = [z(Bb, cfg.max_len, cfg.dec_dim) for _ in range(cfg.dec_layers)]
         self.k_cross = [z(Bb, cfg.tokens, cfg.dec_dim) for _ in range(cfg.dec_layers)]
         self.v_cross = [z(Bb, cfg.tokens, cfg.dec_dim) for _ in range(cfg.dec_layers)]
+        # bookkeeping of the greedy loop, updated by the last kernel of every step (ops.transformer.decode_bookkeep)
+        self.out = torch.full((cfg.max_len, Bb), cfg.pad, dtype=torch.int32, device=device)
+        self.psum = torch.zeros((Bb,), dtype=torch.float32, device=device)
+        self.cnt = torch.zeros((Bb,), dtype=torch.float32, device=device)
+        self.done = torch.zeros((Bb,), dtype=torch.uint8, device=device)
+        on_gpu = torch.device(device).type == "cuda"
+        # "every sequence has emitted eos", written by the device, read by the host without a stream synchronisation
+        self.flag = torch.zeros((1,), dtype=torch.int32, pin_memory=True) if on_gpu else torch.zeros((1,), dtype=torch.int32)
+
+    def reset(self, B: int, cfg) -> None:
+        """Start a new batch of ``B`` sequences (rows beyond B are padding of the batch bucket: done from the start)."""
+        self.tokens.fill_(cfg.bos)
+        self.t.zero_()
+        self.out.fill_(cfg.pad)
+        self.psum.zero_()
+        self.cnt.zero_()
+        self.done.zero_()
+        self.done[B:] = 1
+        if self.flag.is_pinned():
+            torch.cuda.current_stream().synchronize()        # no earlier step may still raise the flag we clear now
+        self.flag.zero_()
 
 
 class _DecodeGraph:

@@ -120,3 +120,4 @@ def _declare(l: ctypes.CDLL) -> None:
     sig("dlamd_dar_register_peer", [vp, i, i, vp])
     sig("dlamd_dar_allreduce_region", [vp, i, ll, i, f, i, vp])
     sig("dlamd_embed_rows", [vp, vp, vp, vp, vp, ll, i, i, i, i, f, vp])
+    sig("dlamd_decode_bookkeep", [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, vp])

@@ -267,8 +267,7 @@ def conv2d_nhwc(
     return y
 
 
-# plain bias-only GEMMs this wide (the decoder's 50 k-row LM head at batch 256: 89.5 us in-repo, 38.2 us hipBLASLt;
-# bench/small_m_probe.py) also go to the library
+# comparison runs only (LIBRARY_GEMM_MIN_ROWS > 0): plain bias-only GEMMs at least this wide go to the library too
 LIBRARY_GEMM_MIN_COLS = 16384
 
 
@@ -290,10 +289,8 @@ def linear_bf16(
     lead = x.shape[:-1]
     K = x.shape[-1]
     N = w.shape[0]
-    # A PLAIN GEMM (bias, optionally the library's own GELU or residual epilogue; no store transform, no im2col)
-    # with many rows is the one case a library kernel is the right tool: hipBLASLt runs the LSTM input projections at 705 TFLOP/s and the ViT
-    # QKV GEMMs at 1135 against 421 / 527 for the 1x1 path of conv_igemm (bench/gemm_probe.py).  Everything
-    # fused, and the small-M decode GEMMs (captured in hipGraphs), stay on the in-repo kernel.
+    # Library GEMMs (hipBLASLt through torch) are a comparison path, off by default (LIBRARY_GEMM_MIN_ROWS = 0): every
+    # linear layer of inference runs on the in-repo kernels below.
     if (LIBRARY_GEMM_MIN_ROWS > 0 and x.is_cuda and out_dtype == torch.bfloat16 and w.is_contiguous()
             and (x.numel() // K >= LIBRARY_GEMM_MIN_ROWS
                  or (N >= LIBRARY_GEMM_MIN_COLS and x.numel() // K >= 64 and act == "none" and res is None))
@@ -320,9 +317,15 @@ def linear_bf16(
         return F.linear(x2d, w, b16).reshape(*lead, N)
     x2 = x.reshape(1, 1, -1, K)
     r2 = None if res is None else res.reshape(1, 1, -1, N)
+    # the MFMA fragment image of the weights is cached on the weight tensor object: it must be taken from ``w`` itself,
+    # not from the 4-d view made below (a fresh object on every call, whose cache dies with it - every small-M linear of
+    # a decode step then rebuilt its fragments: a fill, a copy and a permute per layer, 1.25 of 4.2 ms per step)
+    frag = None
+    if x.is_cuda and USE_WEIGHT_FRAGMENTS and not gemm8_wanted(x2.shape[2], N, K, cfg):
+        frag = weight_fragments(w)
     y = conv2d_nhwc(
         x2, w.view(N, 1, 1, K), bias, act=act, res=r2, res_mode=RES_SAME if res is not None else RES_NONE,
-        out_dtype=out_dtype, cfg=cfg,
+        out_dtype=out_dtype, cfg=cfg, wfrag=frag,
     )
     return y.reshape(*lead, N)
 

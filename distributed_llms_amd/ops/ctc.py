@@ -20,18 +20,30 @@ def row_argmax_reference(logits: torch.Tensor) -> Tuple[torch.Tensor, torch.Tens
     return idx.to(torch.int32), prob
 
 
-def row_argmax(logits: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """argmax and max softmax probability over the last dim. logits: [..., V] bf16/f32."""
+def row_argmax(logits: torch.Tensor, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+               ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """argmax and max softmax probability over the last dim. logits: [..., V] bf16/f32.  ``out`` = (int32 indices,
+    float32 probabilities) of the leading shape: written in place (static buffers of a captured decode step)."""
     if not logits.is_cuda:
-        return row_argmax_reference(logits)
+        idx, prob = row_argmax_reference(logits)
+        if out is not None:
+            out[0].copy_(idx)
+            out[1].copy_(prob)
+            return out
+        return idx, prob
     assert logits.dtype in (torch.bfloat16, torch.float32)
     assert logits.stride(-1) == 1
     V = logits.shape[-1]
     lead = logits.shape[:-1]
     l2 = logits.reshape(-1, V)
     R = l2.shape[0]
-    idx = torch.empty((R,), dtype=torch.int32, device=logits.device)
-    prob = torch.empty((R,), dtype=torch.float32, device=logits.device)
+    if out is not None:
+        idx, prob = out
+        assert idx.dtype == torch.int32 and prob.dtype == torch.float32 and idx.numel() == R and prob.numel() == R
+        assert idx.is_contiguous() and prob.is_contiguous()
+    else:
+        idx = torch.empty((R,), dtype=torch.int32, device=logits.device)
+        prob = torch.empty((R,), dtype=torch.float32, device=logits.device)
     rc = _loader.lib().dlamd_row_argmax(
         _loader.ptr(l2), 1 if logits.dtype == torch.float32 else 0, _loader.ptr(idx), _loader.ptr(prob),
         R, V, l2.stride(0), _loader.stream_ptr(),

@@ -117,3 +117,30 @@ def embed_rows(ids: torch.Tensor, tok: torch.Tensor, pos: torch.Tensor, t: Optio
                                         float(emb_scale), _loader.stream_ptr())
     _loader.check(rc, "dlamd_embed_rows")
     return y
+
+
+def decode_bookkeep(tokens: torch.Tensor, probs: torch.Tensor, t: torch.Tensor, out: torch.Tensor, psum: torch.Tensor,
+                    cnt: torch.Tensor, done: torch.Tensor, flag: torch.Tensor, eos: int) -> None:
+    """Tail of one greedy-decode step, in place: ``out[t, b] = tokens[b]``, ``psum[b] += probs[b]``, ``cnt[b] += 1`` for
+    every sequence that is not done; sequences that emitted ``eos`` become done; ``t += 1``; ``flag[0]`` is set to the
+    step count the first time no sequence is live.  ``out``: int32 [max_len, B]; ``done``: uint8 [B]; ``t``, ``flag``:
+    int32 [1] (``flag`` may live in pinned host memory: the host polls it without synchronising)."""
+    if not tokens.is_cuda:
+        tt = int(t.item())
+        live = done == 0
+        if tt < out.shape[0]:
+            out[tt] = torch.where(live, tokens, out[tt])
+            psum += probs * live
+            cnt += live
+        done |= (live & (tokens == eos)).to(done.dtype)
+        t += 1
+        if not bool((done == 0).any()) and int(flag.item()) == 0:
+            flag.fill_(tt + 1)
+        return
+    assert tokens.dtype == torch.int32 and probs.dtype == torch.float32 and t.dtype == torch.int32
+    assert out.dtype == torch.int32 and out.is_contiguous() and out.shape[1] == tokens.shape[0]
+    assert psum.dtype == torch.float32 and cnt.dtype == torch.float32 and done.dtype == torch.uint8 and flag.dtype == torch.int32
+    rc = _loader.lib().dlamd_decode_bookkeep(_loader.ptr(tokens), _loader.ptr(probs), _loader.ptr(t), _loader.ptr(out),
+                                             _loader.ptr(psum), _loader.ptr(cnt), _loader.ptr(done), flag.data_ptr(),
+                                             tokens.shape[0], out.shape[0], int(eos), _loader.stream_ptr())
+    _loader.check(rc, "dlamd_decode_bookkeep")

@@ -177,9 +177,10 @@ def scan_jpeg(data, max_segments: int = 1 << 20) -> JpegScan:
     buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
     info = JpegInfo()
     tables = np.zeros(JPEG_TABLES_BYTES, dtype=np.uint8)
-    # first pass with a generous fixed buffer; restart-heavy files rarely exceed 64k segments
-    cap = 65536
-    segs = np.zeros(cap, dtype=np.uint32)
+    # first pass with room for the common cases (no restart markers: one segment; a marker per MCU row: a few hundred);
+    # a restart-heavy file is scanned a second time with the exact count
+    cap = 4096
+    segs = np.empty(cap, dtype=np.uint32)
     rc = lib().dljpeg_scan(buf.ctypes.data, buf.size, ctypes.byref(info), tables.ctypes.data, segs.ctypes.data, cap)
     if rc != 0:
         raise PdfError(f"not a decodable JPEG stream (code {rc})")

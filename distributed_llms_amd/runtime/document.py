@@ -9,10 +9,11 @@ This is the MI355X-native ``process_pdf_sync`` (services/ocr_service/ocr_service
     get_content_list / markdown   -> ``content_list`` of {'type': 'text', 'text': ..., 'page_idx': n}
     join 'text' with "\\n\\n"       -> ``combine_text`` (same rule, same markdown fallback)
 
-Page images reach the GPU in the cheapest form available: baseline JPEGs with
-restart markers are shipped compressed and decoded by the GPU kernel; other
-JPEGs go through libjpeg-turbo and Flate images through the native inflater on
-a host thread pool that runs ahead of the GPU by two batches.
+Page images reach the GPU in the cheapest form available: baseline JPEGs (with
+or without restart markers) are shipped compressed and decoded by the GPU
+kernels; progressive / 12-bit JPEGs go through the host decoder and Flate / CCITT
+images through the native decoders on a host thread pool that runs ahead of the
+GPU by two batches.
 """
 from __future__ import annotations
 
@@ -115,23 +116,33 @@ def _line_items(lines: Sequence[TextLine], page_idx: int) -> List[dict]:
     return items
 
 
+def page_content_items(pg: PageResult) -> List[dict]:
+    """Content-list items of one page.  Image items carry ``'figure'``: the position of their crop in
+    ``pg.figures`` (dropped by ``build_content_list``; the packed wire form keeps it, runtime/wire.py)."""
+    items: List[dict] = []
+    figs = sorted(enumerate(pg.figures), key=lambda kf: kf[1].order)
+    # figures keep their place in the reading sequence: Figure.order counts lines + figures before it
+    pos, li = 0, 0
+    for k, fg in figs:
+        take = max(0, fg.order - pos)
+        items += _line_items(pg.lines[li : li + take], pg.page_index)
+        li += take
+        pos += take + 1
+        items.append({"type": "image", "img_path": fg.path, "page_idx": pg.page_index,
+                      "bbox": [round(float(v), 1) for v in fg.box], "figure": k})
+    items += _line_items(pg.lines[li:], pg.page_index)
+    return items
+
+
 def build_content_list(pages: Sequence[PageResult]) -> List[dict]:
     """magic-pdf style content list: {'type': 'text', 'text', 'page_idx'} paragraphs, {'type': 'equation', ...}
     display formulas and {'type': 'image', 'img_path', 'page_idx'} figures in reading order.  Only items with a 'text'
     key reach the combined text (services/ocr_service/ocr_service.py:229-243)."""
     items = []
     for pg in pages:
-        figs = sorted(pg.figures, key=lambda f: f.order)
-        # figures keep their place in the reading sequence: Figure.order counts lines + figures before it
-        pos, li = 0, 0
-        for fg in figs:
-            take = max(0, fg.order - pos)
-            items += _line_items(pg.lines[li : li + take], pg.page_index)
-            li += take
-            pos += take + 1
-            items.append({"type": "image", "img_path": fg.path, "page_idx": pg.page_index,
-                          "bbox": [round(float(v), 1) for v in fg.box]})
-        items += _line_items(pg.lines[li:], pg.page_index)
+        for it in page_content_items(pg):
+            it.pop("figure", None)
+            items.append(it)
     return items
 
 
@@ -177,7 +188,7 @@ def write_figures(pages: Sequence[PageResult], document_id: str, image_writer) -
     from PIL import Image
 
     n = 0
-    safe = re.sub(r"[^A-Za-z0-9_.-]", "_", document_id or "doc")[:80]
+    safe = _safe_name(document_id)
     for pg in pages:
         for k, fg in enumerate(pg.figures):
             if fg.image is None:
@@ -191,14 +202,68 @@ def write_figures(pages: Sequence[PageResult], document_id: str, image_writer) -
     return n
 
 
+def _safe_name(document_id: str) -> str:
+    return re.sub(r"[^A-Za-z0-9_.-]", "_", document_id or "doc")[:80]
+
+
+def assemble_packed(document_id: str, mode: str, shards: Sequence, extra: Dict[int, PageResult], n_pages: int,
+                    t0: Optional[float] = None, image_writer=None) -> "DocumentResult":
+    """``assemble_document`` for results that came back from GPU workers in packed form (runtime/wire.py): the content
+    list and the combined text are built from the item arrays the workers prepared, figure crops arrive as PNG bytes,
+    and ``pages`` materialises ``PageResult`` objects only when somebody reads them.  ``extra``: pages answered in
+    this process (text-layer fallback of pages without an image)."""
+    from .wire import LazyPages
+
+    res = DocumentResult(document_id, mode)
+    where: Dict[int, tuple] = {}
+    for sh in shards:
+        for k, i in enumerate(sh.page_indices()):
+            if sh.present(k):
+                where[i] = (sh, k)
+    safe = _safe_name(document_id)
+    slots, content = [], []
+    for i in sorted(set(where) | set(extra)):
+        hit = where.get(i)
+        if hit is None:
+            pg = extra[i]
+            slots.append((None, -1, pg))
+            for it in page_content_items(pg):
+                it.pop("figure", None)
+                content.append(it)
+            continue
+        sh, k = hit
+        paths: Dict[int, str] = {}
+        f0 = int(sh.fig_off[k])
+        for f in range(f0, int(sh.fig_off[k + 1])):
+            png = sh.figure_png(f)
+            if image_writer is not None and png:
+                paths[f] = f"{safe}/p{i}_f{f - f0}.png"
+                image_writer.write(paths[f], png)
+        slots.append((sh, k, None))
+        content += sh.items(k, i, paths)
+    res.pages = LazyPages(slots, document_id)
+    res.content_list = content
+    res.markdown = "\n\n".join(("![](%s)" % it["img_path"]) if it["type"] == "image" else it["text"] for it in content)
+    res.text = combine_text(content, res.markdown)
+    from ..utils.langid import detect
+
+    res.language, res.language_confidence = detect(res.text)
+    if t0 is not None:
+        res.timings = {"total_s": time.perf_counter() - t0}
+    return res
+
+
 class DocumentPipeline:
     def __init__(self, engine: OcrEngine, decode_threads: Optional[int] = None, prefetch_batches: int = 2,
                  ocr_dpi: int = 300, image_writer=None):
         self.engine = engine
         self.image_writer = image_writer        # ``write(path, data)``: receives figure crops (store.results.LocalFileWriter)
-        n = decode_threads or min(16, max(2, (os.cpu_count() or 4) // max(1, torch.cuda.device_count() or 1)))
+        # sized from the cores this process is allowed on: a GPU worker pinned to its device's share of the host
+        # (utils/affinity.py) gets that share, an unpinned single engine gets the machine
+        n = decode_threads or min(16, max(2, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4)))
         self.pool = ThreadPoolExecutor(max_workers=n, thread_name_prefix="dlamd-decode")
         self.prefetch = prefetch_batches
+        self._pin = bool(engine.on_gpu and getattr(engine, "device", None) is not None)   # a stub engine has no device
         self.timer = StageTimer()
         self.ocr_dpi = ocr_dpi
 
@@ -227,23 +292,27 @@ class DocumentPipeline:
         elif im.codec == reader.CODEC_RAW:
             shape = (im.height, im.width) if im.out_channels == 1 else (im.height, im.width, 3)
             if self.engine.on_gpu:
-                t = torch.empty(shape, dtype=torch.uint8, pin_memory=True)
+                t = torch.empty(shape, dtype=torch.uint8, pin_memory=self._pin)
                 doc.decode_image(im, t.numpy())
                 return PageImage(t, doc_id, i, prior)
             arr = doc.decode_image(im)
         else:
             raise ExtractionError(f"page {i}: unsupported image encoding")
         t = torch.from_numpy(arr)
-        if self.engine.on_gpu:
+        if self._pin:
             t = t.pin_memory()
         return PageImage(t, doc_id, i, prior)
 
-    def _page_batches(self, doc, page_ids, doc_id, priors, skipped: List[int]) -> Iterator[List[PageImage]]:
+    def _page_batches(self, doc, page_ids, doc_id, priors, skipped: List[int],
+                      track: Optional[List[Future]] = None) -> Iterator[List[PageImage]]:
         chunks = [page_ids[a:b] for a, b in balanced_chunks(len(page_ids), self.engine.cfg.max_batch_pages)]
         futs: List[List[Future]] = []
 
         def submit(c):
-            return [self.pool.submit(self._load_page, doc, i, doc_id, None if priors is None else priors[i]) for i in c]
+            fs = [self.pool.submit(self._load_page, doc, i, doc_id, None if priors is None else priors[i]) for i in c]
+            if track is not None:
+                track.extend(fs)
+            return fs
 
         nxt = 0
         while nxt < len(chunks) and nxt < self.prefetch:
@@ -282,6 +351,7 @@ class DocumentPipeline:
         document that cannot be parsed or has no pages yields a result whose ``error`` is set and does not disturb
         the others."""
         states: List[dict] = []
+        loads: List[Future] = []          # every page load handed to the decode pool (they run inside the native reader)
         try:
             def batches() -> Iterator[List[PageImage]]:
                 for k, (pdf_bytes, did, pri) in enumerate(docs):
@@ -301,7 +371,7 @@ class DocumentPipeline:
                     st["mode"] = force_mode or ("txt" if doc.classify().is_text else "ocr")
                     self.timer.add("parse", time.perf_counter() - t0)
                     if st["mode"] == "ocr":
-                        yield from self._page_batches(doc, list(range(st["n"])), f"{k}\x00{did}", pri, st["skipped"])
+                        yield from self._page_batches(doc, list(range(st["n"])), f"{k}\x00{did}", pri, st["skipped"], loads)
 
             for batch_res in self.engine.process_batches(batches()):
                 for pr in batch_res:
@@ -325,6 +395,12 @@ class DocumentPipeline:
                 out.append(res)
             return out
         finally:
+            # after a failure some page loads may still be running: no handle is freed under a thread that uses it
+            for f in loads:
+                f.cancel()
+            from concurrent.futures import wait as _wait
+
+            _wait([f for f in loads if not f.cancelled()], timeout=60.0)
             for st in states:
                 if st["doc"] is not None:
                     st["doc"].close()

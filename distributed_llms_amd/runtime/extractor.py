@@ -13,11 +13,13 @@ from __future__ import annotations
 import logging
 import threading
 import time
+from concurrent.futures import TimeoutError as FutureTimeout
 from typing import Dict, List, Optional
 
 from ..pdf import reader
 from ..store.results import LocalFileWriter
-from .document import DocumentPipeline, DocumentResult, ExtractionError, assemble_document, text_layer_page
+from .document import (DocumentPipeline, DocumentResult, ExtractionError, assemble_document, assemble_packed,
+                       text_layer_page)
 
 logger = logging.getLogger("distributed_llms_amd")
 
@@ -76,12 +78,20 @@ class InlineExtractor(Extractor):
 
     def extract_document(self, pdf_bytes: bytes, document_id: str) -> DocumentResult:
         t0 = time.perf_counter()
+        if hasattr(pdf_bytes, "array") and hasattr(pdf_bytes, "seg"):
+            pdf_bytes = pdf_bytes.array()           # an upload received into shared memory: parsed in place
         doc, n, mode = _open_and_classify(pdf_bytes)
+        fut = None
         try:
             if mode == "txt":
                 pages = [text_layer_page(doc, i, document_id) for i in range(n)]
             else:
-                got = self.service.submit(doc, list(range(n))).result(timeout=self.doc_deadline_s)
+                fut = self.service.submit(doc, list(range(n)))
+                try:
+                    got = fut.result(timeout=self.doc_deadline_s)
+                except FutureTimeout:
+                    self.service.cancel(fut, "deadline")      # the engine drops what it has not started yet
+                    raise ExtractionError(f"document deadline of {self.doc_deadline_s:.0f} s exceeded") from None
                 pages = []
                 for i in range(n):
                     pr = got.get(i)
@@ -91,7 +101,12 @@ class InlineExtractor(Extractor):
                     pages.append(pr)
             return assemble_document(document_id, mode, pages, t0, self.pipeline.image_writer)
         finally:
-            doc.close()
+            # the future can fail (one unreadable page, the deadline) while decode threads are still inside the native
+            # reader for other pages of this document: the handle is freed only after the last of them has returned
+            if fut is None or fut.drained.wait(timeout=60.0):
+                doc.close()
+            else:
+                logger.error(f"{document_id}: pages still in flight after 60 s; the document handle is left open")
 
     def describe(self):
         e = self.pipeline.engine
@@ -105,26 +120,31 @@ class InlineExtractor(Extractor):
 
 
 class PoolExtractor(Extractor):
+    """Front end of the GPU worker pool.  ``pdf_bytes`` may be a ``runtime.workers.ShmDocument`` (an upload that was
+    received into shared memory): it is then parsed in place here and mapped, not copied, by the workers."""
+
     name = "gpu-pool"
+    wants_shm = True          # api/app.py receives uploads for this back end straight into a shared-memory segment
 
     def __init__(self, pool, image_writer: Optional[LocalFileWriter] = None):
         self.pool = pool
         self.image_writer = image_writer
 
-    def extract_document(self, pdf_bytes: bytes, document_id: str) -> DocumentResult:
+    def extract_document(self, pdf_bytes, document_id: str) -> DocumentResult:
+        from .workers import ShmDocument
+
         t0 = time.perf_counter()
-        doc, n, mode = _open_and_classify(pdf_bytes)
+        shm_doc = pdf_bytes if isinstance(pdf_bytes, ShmDocument) else None
+        doc, n, mode = _open_and_classify(shm_doc.array() if shm_doc is not None else pdf_bytes)
         try:
             if mode == "txt":
-                pages = [text_layer_page(doc, i, document_id) for i in range(n)]
-            else:
-                with_image = [i for i in range(n) if doc.main_image(i) is not None]
-                got = self.pool.submit(pdf_bytes, n, with_image).result(timeout=self.pool.doc_deadline_s + 5)
-                pages = []
-                for i in range(n):
-                    pr = got.get(i)
-                    pages.append(pr if pr is not None else text_layer_page(doc, i, document_id, include_invisible=True))
-            return assemble_document(document_id, mode, pages, t0, self.image_writer)
+                return assemble_document(document_id, mode, [text_layer_page(doc, i, document_id) for i in range(n)], t0,
+                                         self.image_writer)
+            with_image = [i for i in range(n) if doc.main_image(i) is not None]
+            got = self.pool.submit(pdf_bytes, n, with_image, doc_name=document_id).result(timeout=self.pool.doc_deadline_s + 5)
+            have = {i for sh in got.shards for k, i in enumerate(sh.page_indices()) if sh.present(k)}
+            extra = {i: text_layer_page(doc, i, document_id, include_invisible=True) for i in range(n) if i not in have}
+            return assemble_packed(document_id, mode, got.shards, extra, n, t0, self.image_writer)
         finally:
             doc.close()
 
@@ -147,6 +167,15 @@ def make_extractor(settings, image_writer: Optional[LocalFileWriter] = None) -> 
         image_writer = LocalFileWriter(settings.image_dir)
     inline_kw = dict(max_wait_ms=getattr(settings, "max_wait_ms", 3.0), doc_deadline_s=getattr(settings, "doc_deadline_s", 600.0),
                      hbm_budget_gb=getattr(settings, "hbm_budget_gb", 0.0))
+
+    if getattr(settings, "worker_sockets", None):
+        # the node's shared worker servers (api/serve.py starts one per GPU): this front end reaches all of them
+        from .workers import WorkerPool
+
+        socks = [t.strip() for t in str(settings.worker_sockets).split(",") if t.strip()]
+        pool = WorkerPool(["unix:" + t for t in socks], fault_inject="", doc_deadline_s=settings.doc_deadline_s,
+                          home=int(getattr(settings, "home_worker", 0)) % max(1, len(socks))).start()
+        return PoolExtractor(pool, image_writer)
 
     from .engine import EngineConfig, OcrEngine
 

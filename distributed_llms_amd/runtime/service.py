@@ -11,7 +11,11 @@ thread as page batches that freely mix documents.  Results are routed back per d
 * decoded-but-not-yet-consumed pages are bounded (``max_pending_pages``) so a thousand-page upload cannot fill host
   memory ahead of the GPU;
 * a failure while loading a page fails that document only; a failure inside the engine fails the documents that had
-  pages in flight and the loop carries on.
+  pages in flight and the loop carries on;
+* a document's future may resolve (one bad page, a cancelled deadline) while other pages of it are still being decoded
+  on the pool or sit in the batcher / the engine with views into the caller's PDF bytes: every job therefore counts
+  its outstanding pages, and ``future.drained`` is set - and the ``on_drained`` callbacks run - only when the last of
+  them has been retired.  Callers close the document and unmap its memory then, never on the future alone.
 """
 from __future__ import annotations
 
@@ -33,7 +37,7 @@ logger = logging.getLogger("distributed_llms_amd")
 
 
 class _Job:
-    __slots__ = ("key", "expected", "pages", "future", "mu", "failed", "on_progress", "t0")
+    __slots__ = ("key", "expected", "pages", "future", "mu", "failed", "on_progress", "t0", "refs", "drained", "_on_drained")
 
     def __init__(self, key: str, expected: int, on_progress: Optional[Callable[[int], None]]):
         self.key = key
@@ -44,6 +48,35 @@ class _Job:
         self.failed = False
         self.on_progress = on_progress
         self.t0 = time.perf_counter()
+        self.refs = expected               # pages not yet retired: loading, queued in the batcher or inside the engine
+        self.drained = threading.Event()
+        self._on_drained: List[Callable[[], None]] = []
+        self.future.drained = self.drained      # what a caller waits for before it frees the document
+        self.future.job_key = key
+        if expected <= 0:
+            self.drained.set()
+
+    def retire(self, n: int = 1) -> bool:
+        """``n`` pages of this job no longer touch the document; True when that was the last of them."""
+        with self.mu:
+            self.refs -= n
+            if self.refs > 0 or self.drained.is_set():
+                return False
+            self.drained.set()
+            cbs, self._on_drained = self._on_drained, []
+        for cb in cbs:
+            try:
+                cb()
+            except Exception:  # noqa: BLE001 - a failing cleanup must not take the calling (engine / decode) thread down
+                logger.exception("drain callback failed")
+        return True
+
+    def add_drained_callback(self, cb: Callable[[], None]) -> None:
+        with self.mu:
+            if not self.drained.is_set():
+                self._on_drained.append(cb)
+                return
+        cb()
 
     def done(self, index: int, result: Optional[PageResult]) -> None:
         with self.mu:
@@ -80,6 +113,7 @@ class EngineService:
         self._seq = 0
         self.recent_batch_sizes = collections.deque(maxlen=64)
         self._outstanding = 0            # pages submitted and not yet handed to the engine (queued or still decoding)
+        self._in_engine: Dict[str, int] = {}     # job key -> pages handed to the engine and not yet returned
         self._slots = threading.Semaphore(max_pending_pages or 8 * self.engine.cfg.max_batch_pages)
         self._closed = False
         self.batches = 0
@@ -93,7 +127,8 @@ class EngineService:
     def submit(self, doc: reader.PdfDocument, page_ids: Sequence[int], priors=None,
                on_progress: Optional[Callable[[int], None]] = None) -> Future:
         """Queue pages of an open document; resolves to {page index: PageResult, or None for a page without an
-        image}.  The caller keeps ``doc`` open until the future is done."""
+        image}.  The caller keeps ``doc`` (and the bytes under it) alive until ``future.drained`` is set - the future
+        itself can resolve earlier, with an error, while other pages of the document are still in flight."""
         with self._mu:
             if self._closed:
                 raise RuntimeError("engine service is closed")
@@ -105,7 +140,6 @@ class EngineService:
             job.future.set_result({})
             self._forget(job)
             return job.future
-        job.future.add_done_callback(lambda _f, j=job: self._forget(j))
         for i in page_ids:
             self.pipeline.pool.submit(self._load_and_push, job, doc, i, None if priors is None else priors[i])
         return job.future
@@ -113,11 +147,35 @@ class EngineService:
     def _forget(self, job: _Job) -> None:
         with self._mu:
             self._jobs.pop(job.key, None)
+            self._in_engine.pop(job.key, None)
+
+    def _retire(self, job: _Job, n: int = 1) -> None:
+        if job.retire(n):
+            self._forget(job)
+
+    def on_drained(self, future: Future, cb: Callable[[], None]) -> None:
+        """Run ``cb`` once no page of the job behind ``future`` is loading, queued or inside the engine (at once when
+        that is already so).  It runs on whichever thread retires the last page: keep it short."""
+        with self._mu:
+            job = self._jobs.get(getattr(future, "job_key", ""))
+        if job is None:
+            cb()
+        else:
+            job.add_drained_callback(cb)
+
+    def cancel(self, future: Future, reason: str = "cancelled") -> None:
+        """Give up on a submitted job (deadline, client gone): its future fails, pages still waiting are dropped at
+        the next batch pop and pages inside the engine finish unobserved."""
+        with self._mu:
+            job = self._jobs.get(getattr(future, "job_key", ""))
+        if job is not None:
+            job.fail(RuntimeError(reason))
 
     def _load_and_push(self, job: _Job, doc: reader.PdfDocument, i: int, prior) -> None:
         if job.failed:
             with self._mu:
                 self._outstanding -= 1
+            self._retire(job)
             return
         self._slots.acquire()
         pushed = False
@@ -137,6 +195,7 @@ class EngineService:
                 self._slots.release()
                 with self._mu:
                     self._outstanding -= 1
+                self._retire(job)        # last: the native reader is no longer inside this page
 
     # ------------------------------------------------------------------ engine thread
     def _next_batch(self, block: bool):
@@ -150,14 +209,22 @@ class EngineService:
         for _ in items:
             self._slots.release()
         live: List[PageImage] = []
+        dropped: List[_Job] = []
         with self._mu:
             for p in items:
                 job = self._jobs.get(p.doc_id)
                 if job is not None and not job.failed:
                     live.append(p)
+                    self._in_engine[job.key] = self._in_engine.get(job.key, 0) + 1
+                elif job is not None:
+                    dropped.append(job)
+        n_popped = len(items)
+        del items
+        for job in dropped:
+            self._retire(job)
         self.batches += 1
         self.pages_in_batches += len(live)
-        self.recent_batch_sizes.append(len(items))
+        self.recent_batch_sizes.append(n_popped)
         return live or None
 
     def _pop_balanced(self, block: bool):
@@ -192,19 +259,32 @@ class EngineService:
                     for pr in results:
                         with self._mu:
                             job = self._jobs.get(pr.doc_id)
+                            if job is not None:
+                                self._in_engine[job.key] = self._in_engine.get(job.key, 1) - 1
                         if job is not None:
                             job.done(pr.page_index, pr)
+                            self._retire(job)
                 return
             except BaseException as e:  # noqa: BLE001 - fail what was in flight, keep serving
                 logger.error(f"engine loop error: {type(e).__name__}: {e}")
                 with self._mu:
                     jobs = list(self._jobs.values())
+                    lost, self._in_engine = self._in_engine, {}
                 for job in jobs:
                     job.fail(RuntimeError(f"engine failure: {type(e).__name__}: {e}"))
+                # the pipeline's batches went down with the generator: their pages hold no view any more
+                for job in jobs:
+                    if lost.get(job.key, 0) > 0:
+                        self._retire(job, lost[job.key])
                 if self._closed:
                     return
 
     # ------------------------------------------------------------------ lifecycle / stats
+    def load(self) -> int:
+        """Pages this service still owes: decoding, queued in the batcher or inside the engine."""
+        with self._mu:
+            return max(0, self._outstanding) + sum(v for v in self._in_engine.values() if v > 0)
+
     def stats(self) -> Dict[str, float]:
         s = dict(self.batcher.stats())
         s["engine_batches"] = self.batches
@@ -214,7 +294,7 @@ class EngineService:
         # cumulative seconds per pipeline stage (host decode wait, detector submit / wait, recogniser, finish) and the
         # HBM this process holds: exported per worker through GET /metrics
         s["stage_seconds"] = {**self.pipeline.timer.summary(), **self.engine.timer.summary()}
-        if self.engine.on_gpu:
+        if self.engine.on_gpu and getattr(self.engine, "device", None) is not None:
             s["hbm_allocated_bytes"] = int(torch.cuda.memory_allocated(self.engine.device))
             s["hbm_reserved_bytes"] = int(torch.cuda.memory_reserved(self.engine.device))
         return s

@@ -39,13 +39,18 @@ def test_bench_under_torchrun_four_ranks_gloo():
     # whole-job aggregate: pages of all ranks over the slowest rank's time
     assert out["value"] == pytest.approx(2 * 2 * 4 / (out["ms_per_step"] * 2 / 1000.0), rel=1e-3)
     assert "without restart markers" in out["data"]
+    assert out["config"]["host_cpu_s_per_100_pages"] > 0          # CPU seconds of a rank per 100 pages (all its threads)
 
 
 def test_bench_via_pool_under_torchrun():
     out = _run("bench.py", 2, "--cpu", "--via-pool", "--gpus", "2", "--steps", "1", "--warmup", "1", "--pages-per-doc", "3")
     assert KEYS <= set(out)
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "pool2"
-    assert out["config"]["pool"]["workers"] == 2 and out["config"]["pool"]["pages_done"] == 2 * 2 * 3
+    # two front-end processes, each reaching both engine workers; rank 0's own documents: (warm-up + 1 step) x 3 pages
+    pool = out["config"]["pool"]
+    assert pool["workers"] == 2 and pool["shared_workers"] and pool["pages_done"] == 2 * 3 and pool["restarts"] == 0
+    assert out["value"] == pytest.approx(2 * 3 / (out["ms_per_step"] / 1000.0), rel=1e-3)
+    assert out["config"]["front_end_cpu_s_per_100_pages"] > 0
 
 
 @pytest.mark.parametrize("script,flags", [

@@ -24,6 +24,22 @@ def _free_port():
     return p
 
 
+def _init(rank, world, port, **env):
+    """One-GPU box: every rank uses cuda:0 and the handles travel over gloo (RCCL refuses two ranks on one device).
+    With DLAMD_TEST_MULTI_GPU=1 (tests/test_multigpu.py, needs >= world devices): one rank per device over RCCL - the
+    layout the kernels are built for.  Returns the rank's device index."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", **env)
+    multi = os.environ.get("DLAMD_TEST_MULTI_GPU") == "1"
+    dev = rank if multi else 0
+    torch.cuda.set_device(dev)
+    if multi:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dev
+
+
 def _oracle(parts, scale, dtype):
     acc = torch.zeros_like(parts[0], dtype=torch.float32)
     for p in parts:
@@ -32,10 +48,7 @@ def _oracle(parts, scale, dtype):
 
 
 def _rank_main(rank, world, port, out_dir, starve):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      HSA_ENABLE_IPC_MODE_LEGACY="0")
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = _init(rank, world, port)
     from distributed_llms_amd.parallel.direct import DirectAllReduce
 
     ar = DirectAllReduce(max_bytes=8 << 20, blocks=32)
@@ -104,10 +117,7 @@ def test_direct_allreduce_bounded_spin_reports_missing_peer():
 
 
 def _region_rank(rank, world, port, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      HSA_ENABLE_IPC_MODE_LEGACY="0", DLAMD_DAR_SPIN_LIMIT=str(1 << 22))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = _init(rank, world, port, DLAMD_DAR_SPIN_LIMIT=str(1 << 22))
     from distributed_llms_amd.parallel.direct import DirectAllReduce, DirectAllReduceError
 
     ar = DirectAllReduce(max_bytes=4096, blocks=32)
@@ -168,10 +178,7 @@ def test_registered_buffers_are_reduced_in_place(world):
 
 
 def _ddp_rank(rank, world, port, out_dir, mode):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      HSA_ENABLE_IPC_MODE_LEGACY="0")
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = _init(rank, world, port)
     from distributed_llms_amd.parallel.ddp import BucketedDDP
 
     torch.manual_seed(0)
@@ -230,10 +237,7 @@ def test_supported_predicate():
 
 
 def _trainer_rank(rank, world, port, out_dir, mode):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      HSA_ENABLE_IPC_MODE_LEGACY="0")
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = _init(rank, world, port)
     from distributed_llms_amd.models.crnn import CRNN
     from distributed_llms_amd.parallel.comm import DistEnv
     from distributed_llms_amd.train.trainer import CTCTrainer, TrainConfig
@@ -242,7 +246,9 @@ def _trainer_rank(rank, world, port, out_dir, mode):
     model = CRNN(hidden=64, widths=(8, 16, 16, 16, 32, 32))
     cfg = TrainConfig(batch_size=8, width=96, lr=3e-3, vocab=3, max_chars=5, font_px=28, warmup_steps=0, bucket_mb=0.05,
                       dp_mode=mode, amp=False)
-    tr = CTCTrainer(model, cfg, device="cuda:0", env=DistEnv(rank, world, 0, torch.device("cuda:0"), "gloo"))
+    tr = CTCTrainer(model, cfg, device=f"cuda:{dev}",
+                    env=DistEnv(rank, world, dev, torch.device(f"cuda:{dev}"),
+                                "nccl" if os.environ.get("DLAMD_TEST_MULTI_GPU") == "1" else "gloo"))
     losses = []
     for s in range(4):
         losses.append(tr.train_step(*tr.synthetic_batch(s)))
@@ -275,10 +281,7 @@ def test_ctc_trainer_dp2_direct_allreduce_matches_process_group_allreduce():
 
 
 def _late_peer_rank(rank, world, port, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      HSA_ENABLE_IPC_MODE_LEGACY="0")
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = _init(rank, world, port)
     import time
 
     from distributed_llms_amd.parallel.ddp import BucketedDDP

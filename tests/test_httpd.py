@@ -222,3 +222,142 @@ def test_scope_fields_match_what_the_framework_expects():
     assert seen["query_string"] == b"q=1&r=%20" and seen["http_version"] == "1.1" and seen["scheme"] == "http"
     assert (b"x-thing", b"Val") in seen["headers"] and seen["body"] == b"hello"
     assert seen["client"][0] == "127.0.0.1" and seen["server"][1] == r.port
+
+
+def test_ambiguous_request_framing_is_rejected(service):
+    """Where two parsers in a row (a load balancer, then this server) could disagree about where a request ends, the
+    request is refused: Content-Length with Transfer-Encoding, repeated Content-Length, codings other than exactly
+    'chunked', chunk sizes that int(x, 16) would accept but the grammar does not."""
+    r, _, _ = service
+    base = b"POST /extract HTTP/1.1\r\nhost: x\r\n"
+    bad_heads = [
+        base + b"content-length: 5\r\ntransfer-encoding: chunked\r\n\r\n",
+        base + b"content-length: 5\r\ncontent-length: 5\r\n\r\nhello",
+        base + b"content-length: 5\r\ncontent-length: 6\r\n\r\nhello",
+        base + b"transfer-encoding: xchunked\r\n\r\n",
+        base + b"transfer-encoding: gzip, chunked\r\n\r\n",
+        base + b"transfer-encoding: chunked\r\ntransfer-encoding: chunked\r\n\r\n",
+        base + b"content-length: 99999999999999999999\r\n\r\n",
+    ]
+    for raw in bad_heads:
+        s = socket.create_connection(("127.0.0.1", r.port))
+        s.sendall(raw)
+        got = s.recv(4096)
+        assert got.startswith(b"HTTP/1.1 400"), (raw[-60:], got[:40])
+        s.close()
+    for size in (b"-1", b"+5", b"0x10", b"1_0", b"", b"11111111111111111", b"5 5"):
+        s = socket.create_connection(("127.0.0.1", r.port))
+        s.sendall(base + b"content-type: multipart/form-data; boundary=x\r\ntransfer-encoding: chunked\r\n\r\n" + size + b"\r\nhello\r\n0\r\n\r\n")
+        got = s.recv(4096)
+        assert got.startswith(b"HTTP/1.1 400"), (size, got[:40])
+        s.close()
+    c = http.client.HTTPConnection("127.0.0.1", r.port, timeout=10)
+    c.request("GET", "/health")
+    assert c.getresponse().status == 200
+
+
+def test_pipelined_bytes_behind_a_running_request_are_bounded():
+    """A client that keeps writing while its first request is still being answered is stopped by back-pressure: the
+    server holds a bounded number of its bytes, not everything it cares to send."""
+    release = threading.Event()
+    protos = []
+
+    async def app(scope, receive, send):
+        if scope["type"] != "http":
+            return
+        await receive()
+        while not release.is_set():
+            await asyncio.sleep(0.01)
+        await send({"type": "http.response.start", "status": 200, "headers": [(b"content-length", b"2")]})
+        await send({"type": "http.response.body", "body": b"ok"})
+
+    with Running(app) as r:
+        s = socket.create_connection(("127.0.0.1", r.port))
+        s.sendall(b"GET /slow HTTP/1.1\r\nhost: x\r\n\r\n")
+        s.setblocking(False)
+        junk = b"GET /again HTTP/1.1\r\nhost: x\r\nx-pad: " + b"a" * 900 + b"\r\n\r\n"
+        sent, t_end = 0, time.time() + 3.0
+        while time.time() < t_end and sent < 64 << 20:
+            try:
+                sent += s.send(junk)
+            except BlockingIOError:
+                time.sleep(0.01)
+        protos = list(r.server.connections)
+        assert protos and all(p.hlen <= httpd.MAX_PIPELINED + 2 * httpd.MAX_HEADER for p in protos)
+        assert sent < 32 << 20, "the socket must have filled up: the server stopped reading"
+        release.set()
+        s.setblocking(True)
+        s.settimeout(10)
+        assert s.recv(4096).startswith(b"HTTP/1.1 200")
+        s.close()
+
+
+def test_body_sink_receives_the_upload_in_place():
+    """An application that names the body's destination gets memoryview slices OF that buffer from receive():
+    nothing is copied between the socket and the buffer."""
+    got = {}
+
+    async def app(scope, receive, send):
+        if scope["type"] != "http":
+            return
+        n = scope["extensions"]["dlamd.body_sink"]["length"]
+        buf = bytearray(n)
+        assert scope["extensions"]["dlamd.body_sink"]["set"](buf)
+        pos = in_place = 0
+        while True:
+            m = await receive()
+            b = m["body"]
+            if len(b):
+                if isinstance(b, memoryview) and b.obj is buf:
+                    in_place += len(b)
+                else:
+                    buf[pos : pos + len(b)] = b           # bytes that shared a segment with the request head
+                pos += len(b)
+            if not m["more_body"]:
+                break
+        got.update(buf=bytes(buf), in_place=in_place, n=n)
+        await send({"type": "http.response.start", "status": 200, "headers": [(b"content-length", b"0")]})
+        await send({"type": "http.response.body", "body": b""})
+
+    payload = bytes(range(251)) * 20000                     # ~5 MB
+    with Running(app) as r:
+        c = http.client.HTTPConnection("127.0.0.1", r.port, timeout=30)
+        c.request("POST", "/up", body=payload)
+        assert c.getresponse().status == 200
+    assert got["buf"] == payload and got["in_place"] > 0.9 * len(payload)
+
+
+def test_upload_received_into_shared_memory_reaches_the_extractor_unchanged(tmp_path):
+    """With a worker-pool back end the upload is received into a shared-memory segment; the extractor gets a
+    ShmDocument that points at the file part inside it, and the segment is reused for the next upload."""
+    import os
+
+    from distributed_llms_amd.runtime.workers import ShmDocument
+
+    seen = []
+
+    class ShmEcho(EchoExtractor):
+        wants_shm = True
+
+        def extract(self, pdf_bytes, document_id, document_hash=None):
+            assert isinstance(pdf_bytes, ShmDocument)
+            seen.append(pdf_bytes.seg.name)
+            raw = bytes(pdf_bytes.view())
+            return {"status": "completed", "result": f"{len(raw)} {hashlib.sha256(raw).hexdigest()}", "pages": 1}
+
+    st, rs = MemoryStatusStore(), MemoryResultStore()
+    app = create_app(Settings(store="memory", output_dir=str(tmp_path), num_gpus=0, node_id="t"), st, rs, ShmEcho())
+    with Running(app) as r:
+        c = http.client.HTTPConnection("127.0.0.1", r.port, timeout=30)
+        for k in range(3):
+            pdf = b"%PDF-1.4\n" + bytes([k]) * 700_000 + b"\r\n--not the boundary\r\n" + b"y" * 1000
+            body, ct = encode_multipart({"document_id": f"s{k}"}, {"file": ("a.pdf", pdf, "application/pdf")})
+            c.request("POST", "/extract", body=body, headers={"content-type": ct})
+            resp = c.getresponse()
+            assert resp.status == 200 and json.loads(resp.read()) == {"status": "ok"}
+            assert _wait_done(c, f"s{k}") == "completed"
+            assert rs.find(f"s{k}")["combined_text"] == f"{len(pdf)} {hashlib.sha256(pdf).hexdigest()}"
+            assert st.get(f"s{k}")["document_hash"] == hashlib.sha256(pdf).hexdigest()
+        assert len(set(seen)) == 1, "the segment of a finished upload serves the next one"
+        assert os.path.exists("/dev/shm/" + seen[0])
+    assert not os.path.exists("/dev/shm/" + seen[0]), "released at shutdown"

@@ -153,3 +153,58 @@ def test_image_layout_ships_and_loads_the_trained_weights(tmp_path, monkeypatch)
     env.update(OCR_NUM_GPUS="0", OCR_STORE="memory", PYTHONPATH=str(app))
     p = subprocess.run([sys.executable, "-c", code], cwd=app, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "WEIGHTS-LOADED" in p.stdout, p.stderr[-3000:]
+
+
+@pytest.mark.timeout(240)
+def test_shared_worker_servers_behind_several_front_ends(tmp_path, monkeypatch):
+    """The node layout of a multi-GPU box, with stub engines: two worker servers, three front ends on one port,
+    every front end reaching every worker.  Scanned uploads are received into shared memory and extracted; a worker
+    server that dies is restarted by the supervisor and documents keep completing."""
+    monkeypatch.setenv("OCR_OUTPUT_DIR", str(tmp_path / "out"))
+    monkeypatch.setenv("OCR_DOTENV", "/nonexistent")
+    monkeypatch.delenv("REDIS_HOST", raising=False)
+    monkeypatch.delenv("MONGO_CONNECTION_STRING", raising=False)
+    sup = serve.Supervisor(0, "127.0.0.1", 3, embedded_redis=True, stub_gpus=2, stub_pages_per_s=400.0).start()
+    try:
+        assert sup.shared and len(sup.workers) == 2 and len(sup.children) == 3
+        env = sup.child_env(2)
+        assert env["OCR_HOME_WORKER"] == "0" and env["OCR_NUM_GPUS"] == "0" and len(env["OCR_WORKER_SOCKETS"].split(",")) == 2
+        t0 = time.time()
+        while time.time() - t0 < 120:
+            try:
+                if _get(sup.port, "/health")[0] == 200:
+                    break
+            except OSError:
+                time.sleep(0.2)
+        pages = [synth.render_page(i, size=(248, 350), font_px=10, margin=16)[0] for i in range(3)]
+        pdf = synth.make_scanned_pdf([pages[i % 3] for i in range(12)], codec="jpeg", dpi=30)
+
+        def run(ids):
+            for d in ids:
+                body, ctype = encode_multipart({"document_id": d}, {"file": (f"{d}.pdf", pdf, "application/pdf")})
+                c = http.client.HTTPConnection("127.0.0.1", sup.port, timeout=60)
+                c.request("POST", "/extract", body=body, headers={"content-type": ctype})
+                r = c.getresponse()
+                assert r.status == 200 and json.loads(r.read()) == {"status": "ok"}
+                c.close()
+            for d in ids:
+                for _ in range(1500):
+                    st, body, _ = _get(sup.port, f"/check-status/{d}")
+                    if st == 200 and json.loads(body)["status"] != "processing":
+                        break
+                    time.sleep(0.02)
+                assert json.loads(body)["status"] == "completed", (d, body)
+                st, body, _ = _get(sup.port, f"/result/{d}")
+                assert st == 200 and "quick brown fox" in json.loads(body)["text"]
+
+        run([f"scan-{i}" for i in range(8)])
+        victim = sup.workers[0]
+        victim.kill()
+        victim.wait(timeout=10)
+        sup.poll_once()
+        assert sup.workers[0].pid != victim.pid and sup.worker_restarts == 1
+        run([f"after-{i}" for i in range(6)])
+    finally:
+        sup.shutdown()
+    kids = [p.pid for p in sup.children.values()]
+    assert not [n for n in os.listdir("/dev/shm") if any(n.startswith(f"dlamd-{k}-") for k in kids)], "segments left behind"
