@@ -67,7 +67,8 @@ def parse_args():
                     help="largest page batch; a document is cut into the fewest equal batches below it (100 pages: 34 + 33 + 33)")
     ap.add_argument("--input", choices=["pdf", "raster"], default="pdf",
                     help="pdf: timed region starts from PDF bytes (parse + image decode); raster: decoded u8 pages")
-    ap.add_argument("--codec", choices=["jpeg", "flate"], default="jpeg")
+    ap.add_argument("--codec", choices=["jpeg", "flate", "flate-png", "ccitt"], default="jpeg",
+                    help="page image encoding: DCT (default), Flate (zlib level 1), Flate with PNG predictors, CCITT Group 4 (bilevel)")
     ap.add_argument("--restart-blocks", type=int, default=0,
                     help="MCUs per JPEG restart interval; 0 (default) = no restart markers, what scanners write")
     ap.add_argument("--color", choices=["gray", "rgb"], default="gray", help="colour space of the page images")
@@ -287,13 +288,28 @@ def main():
         pages = [np.clip(p[..., None].astype(np.float32) * tint, 0, 255).astype(np.uint8) for p in pages]
     images = ("%s %s" % (args.color, "JPEG q85 without restart markers" if args.restart_blocks == 0 else
                          "JPEG q85 with a restart marker every %d MCUs" % args.restart_blocks)
-              if args.codec == "jpeg" else "%s Flate (zlib level 1)" % args.color)
+              if args.codec == "jpeg" else ("bilevel CCITT Group 4" if args.codec == "ccitt" else
+                                            "%s Flate (zlib level 1%s)" % (args.color, ", PNG predictors" if args.codec == "flate-png" else "")))
     if args.input == "pdf":
         enc = None
         if args.codec == "jpeg":
             enc_d = [synth.encode_page_jpeg(pages[i], restart_blocks=args.restart_blocks) for i in range(n_dist)]
             enc = [enc_d[i % n_dist] for i in range(args.pages_per_doc)]
-        pdf_bytes = synth.make_scanned_pdf(pages, codec=args.codec, encoded=enc)
+        if args.codec == "ccitt":
+            import zlib  # noqa: F401 - (kept beside the other encoders)
+
+            enc_d = [synth.encode_page_ccitt_g4(pages[i]) for i in range(n_dist)]
+            pdf_bytes = synth.make_scanned_pdf(pages, codec="ccitt", encoded_ccitt=[enc_d[i % n_dist] for i in range(args.pages_per_doc)])
+        elif args.codec.startswith("flate"):
+            import zlib
+
+            pred = 15 if args.codec == "flate-png" else 1
+            raw_d = [synth.png_predict_rows(pages[i]) if pred == 15 else np.ascontiguousarray(pages[i]).tobytes() for i in range(n_dist)]
+            enc_d = [zlib.compress(r, 1) for r in raw_d]
+            pdf_bytes = synth.make_scanned_pdf(pages, codec="flate", encoded=[enc_d[i % n_dist] for i in range(args.pages_per_doc)],
+                                               predictor=pred)
+        else:
+            pdf_bytes = synth.make_scanned_pdf(pages, codec=args.codec, encoded=enc)
         run = lambda: pipe.process_pdf(pdf_bytes, "bench", layout_priors=priors)
     else:
         pinned = [torch.from_numpy(rendered[i][0]).pin_memory() if use_gpu else torch.from_numpy(rendered[i][0])

@@ -395,6 +395,12 @@ int dlpdf_image_jpeg_bytes(void* hp, int page, int idx, uint8_t** out, size_t* l
 
 void dlpdf_free(void* p) { free(p); }
 
+// The in-repo zlib-stream decoder on its own (tests, benchmarks): bytes written to dst, or -1 when it refuses the
+// stream (callers inside the library then use zlib).
+long long dlpdf_fast_inflate(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
+  return fastinflate::inflate_zlib(src, n, dst, cap);
+}
+
 // Decode a non-JPEG image to 8-bit gray (out_channels 1) or RGB (3), row-major, into dst.
 // Thread-safe after the page has been analysed.  Returns bytes written or < 0.
 long long dlpdf_image_decode(void* hp, int page, int idx, uint8_t* dst, size_t dst_len) {
@@ -410,6 +416,19 @@ long long dlpdf_image_decode(void* hp, int page, int idx, uint8_t* dst, size_t d
   }
   if (im.codec != 0) return -3;
   try {
+    // the common scanner layout - one FlateDecode filter, no predictor, 8-bit gray or RGB - is inflated straight into
+    // the caller's (pinned) buffer: no intermediate string, no second pass over the 9-26 MB of raster
+    if (im.filters.size() == 1 && (im.filters[0] == "FlateDecode" || im.filters[0] == "Fl") && im.parms[0][0] <= 1 &&
+        im.bpc == 8 && !im.indexed && !im.invert && !im.mask && (im.ncomp == 1 || im.ncomp == 3)) {
+      const size_t need = (size_t)im.width * im.height * im.ncomp;
+      if (dst_len >= need) {
+        const uint8_t* p = im.owned ? (const uint8_t*)im.owned->data() : h->doc->data() + im.off;
+        const size_t len = im.owned ? im.owned->size() : im.len;
+        const long long got = fastinflate::inflate_zlib(p, len, dst, need);
+        if (got == (long long)need) return (long long)need;
+        // short, long or damaged streams: the general path below pads / truncates / tolerates as before
+      }
+    }
     std::string raw = run_filters(h->doc->data(), im);
     const int W = im.width, H = im.height, nc = im.ncomp, bpc = im.bpc;
     const bool color = (!im.indexed && (nc == 3 || nc == 4)) || (im.indexed && im.palette_comps >= 3);

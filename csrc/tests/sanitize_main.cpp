@@ -14,6 +14,8 @@
 #include <thread>
 #include <vector>
 
+#include <zlib.h>
+
 extern "C" {
 struct DlpdfPageInfo {
   double width_pt, height_pt;
@@ -42,6 +44,7 @@ int dlpdf_image_jpeg_bytes(void* h, int page, int idx, uint8_t** out, size_t* le
 void dlpdf_free(void* p);
 long long dlpdf_image_decode(void* h, int page, int idx, uint8_t* dst, size_t dst_len);
 int dlpdf_classify(void* h, DlpdfClassify* out);
+long long dlpdf_fast_inflate(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
 int dljpeg_sizes(int* info_size, int* tables_size);
 int dljpeg_scan(const uint8_t* d, size_t n, void* info, void* tables, uint32_t* seg_offsets, int max_segs);
 
@@ -250,6 +253,60 @@ static void jpeg_crafted() {
   printf("  jpeg: crafted DHT/SOS headers refused, %d of 20000 mutated headers still parsed\n", accepted);
 }
 
+// The in-repo inflater against zlib's deflate: exact round trips at several compression settings, then truncated and
+// bit-flipped streams with tight output buffers - it may refuse them (-1), it must never write past ``cap`` (the
+// buffer is heap-allocated at exactly that size, so ASan sees one byte too many).
+static void inflate_stress() {
+  std::mt19937 rng(4242);
+  std::vector<std::vector<uint8_t>> raws;
+  raws.push_back(std::vector<uint8_t>(200000, 255));                           // paper
+  std::vector<uint8_t> noisy(300000);
+  for (size_t i = 0; i < noisy.size(); ++i) noisy[i] = (uint8_t)(((i / 700) % 5 == 0 ? 30 : 235) + (rng() % 9));
+  raws.push_back(noisy);
+  std::vector<uint8_t> rnd(70000);
+  for (auto& b : rnd) b = (uint8_t)rng();
+  raws.push_back(rnd);
+  raws.push_back(std::vector<uint8_t>());
+  long long refused = 0, total = 0;
+  for (const auto& raw : raws)
+    for (int level : {0, 1, 6, 9})
+      for (int strategy : {Z_DEFAULT_STRATEGY, Z_HUFFMAN_ONLY, Z_RLE, Z_FIXED}) {
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (deflateInit2(&zs, level, Z_DEFLATED, 15, 8, strategy) != Z_OK) exit(6);
+        std::vector<uint8_t> z(deflateBound(&zs, (uLong)raw.size()) + 16);
+        zs.next_in = const_cast<Bytef*>(raw.data());
+        zs.avail_in = (uInt)raw.size();
+        zs.next_out = z.data();
+        zs.avail_out = (uInt)z.size();
+        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) exit(6);
+        z.resize(zs.total_out);
+        deflateEnd(&zs);
+        {
+          std::vector<uint8_t> out(raw.size() ? raw.size() : 1);
+          const long long got = dlpdf_fast_inflate(z.data(), z.size(), out.data(), raw.size());
+          if (got != (long long)raw.size() || (raw.size() && memcmp(out.data(), raw.data(), raw.size()))) {
+            fprintf(stderr, "inflate round trip failed (level %d strategy %d size %zu got %lld)\n", level, strategy, raw.size(), got);
+            exit(6);
+          }
+        }
+        for (int it = 0; it < 60; ++it) {
+          std::vector<uint8_t> m = z;
+          const int kind = it % 3;
+          if (kind == 0 && m.size() > 3) m.resize(2 + rng() % (m.size() - 2));                 // truncated
+          else if (m.size() > 2) for (int k = 0; k < 1 + (int)(rng() % 4); ++k) m[2 + rng() % (m.size() - 2)] ^= (uint8_t)(1u << (rng() % 8));
+          const size_t cap = kind == 2 ? (raw.size() ? rng() % raw.size() : 0) : raw.size() + rng() % 64;
+          uint8_t* out = (uint8_t*)malloc(cap ? cap : 1);
+          const long long got = dlpdf_fast_inflate(m.data(), m.size(), out, cap);
+          if (got > (long long)cap) { fprintf(stderr, "inflate reported more bytes than the buffer holds\n"); exit(6); }
+          refused += got < 0;
+          ++total;
+          free(out);
+        }
+      }
+  printf("  inflate: round trips exact; %lld of %lld damaged / short-buffer streams refused, none overran\n", refused, total);
+}
+
 int main(int argc, char** argv) {
   int iters = 1500;
   for (int i = 1; i < argc; ++i) {
@@ -264,6 +321,7 @@ int main(int argc, char** argv) {
     fuzz_pdf(pdf, iters, 1234u + (uint32_t)i);
   }
   jpeg_crafted();
+  inflate_stress();
   batcher_stress();
   bpe_stress();
   printf("sanitize: OK\n");

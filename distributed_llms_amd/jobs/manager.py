@@ -112,9 +112,11 @@ class JobManager:
                 saved = await self._io(self.save_results, document_id, result)
                 if not saved:
                     raise RuntimeError("result store rejected the document")
-                await self._io(self.status.update, document_id, {
-                    "status": "completed", "document_hash": document_hash, "result": result["result"],
-                    "completed_at": _now(), "owner": self.node_id})
+                final = {"status": "completed", "document_hash": document_hash, "result": result["result"],
+                         "completed_at": _now(), "owner": self.node_id}
+                if result.get("warnings"):
+                    final["warnings"] = result["warnings"]      # e.g. pages whose image stream was damaged
+                await self._io(self.status.update, document_id, final)
                 metrics.STAGE_SECONDS.labels("store").observe(time.perf_counter() - t1)
                 metrics.DOCUMENTS.labels("completed").inc()
                 metrics.PAGES.inc(int(result.get("pages", 0) or 0))

@@ -119,6 +119,12 @@ class CRNN(nn.Module):
             ld = None if lens is None else lens.to(y.device, torch.int32)
             y = bilstm_train(y, self.rnn1, ld)
             y = bilstm_train(y, self.rnn2, ld)
+            if self.own_conv_train and self.training:
+                # the classifier and its gradients on the in-repo kernels as well: with the convolutions, batch norm,
+                # recurrences, projections, CTC loss and AdamW already there, no library GEMM is left in the step
+                from ..ops.linear_train import linear_train
+
+                return linear_train(y, self.fc.weight, self.fc.bias).float()
             if not torch.is_autocast_enabled():
                 y = y.to(self.fc.weight.dtype)
         elif lens is not None:

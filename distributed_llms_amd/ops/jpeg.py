@@ -141,16 +141,35 @@ def _decode_self_synchronising(streams: Sequence[np.ndarray], scans: Sequence[Jp
                                            _loader.stream_ptr()), "dlamd_jpeg_sync_finish")
     res = []
     oo = 0
+    # blocks the synchronised decode accounted for, per stream (one reduction for the whole call): equals
+    # mcus * blocks_per_mcu for an intact stream; a truncated / damaged scan, or a seam pass that ran into its limit,
+    # comes out short and the page holds garbage from there on (``blocks_short`` lets the caller find out)
+    counted = sub[1].sum(dim=1, dtype=torch.int32)
     for k, sc in enumerate(scans):
         Wb, Hb = geo[k]
         plane = out[oo : oo + sizes[k]].view(Hb * 8, Wb * 8)
         t = plane[: sc.info.height, : sc.info.width]
         t._dlamd_keep = (dev, coef, sub, dc)  # type: ignore[attr-defined]
-        # blocks the synchronised decode accounted for; equals mcus * blocks_per_mcu for an intact stream
-        t._dlamd_blocks = (sub[1, k], scans[k].info.mcus_x * scans[k].info.mcus_y * scans[k].info.blocks_per_mcu)  # type: ignore[attr-defined]
+        t._dlamd_blocks = (counted, k, scans[k].info.mcus_x * scans[k].info.mcus_y * scans[k].info.blocks_per_mcu)  # type: ignore[attr-defined]
         res.append(t)
         oo += sizes[k]
     return res
+
+
+def blocks_short(pages: Sequence[Optional[torch.Tensor]]):
+    """For decoded pages of ONE ``decode_jpeg_batch_gpu`` call: (device int32 tensor of decoded block counts or None,
+    [(position in ``pages``, row in that tensor, expected count)]).  The caller copies the tensor to the host with its
+    other results and compares: a page whose count differs from the expectation was not decoded completely."""
+    counted, rows = None, []
+    for pos, t in enumerate(pages):
+        info = getattr(t, "_dlamd_blocks", None) if t is not None else None
+        if info is None:
+            continue
+        if counted is None:
+            counted = info[0]
+        if info[0] is counted:
+            rows.append((pos, int(info[1]), int(info[2])))
+    return counted, rows
 
 
 def _decode_restart_segments(streams: Sequence[np.ndarray], scans: Sequence[JpegScan], device: torch.device

@@ -1,0 +1,71 @@
+"""Linear layer for TRAINING on the in-repo kernels: forward, data gradient and weight gradient as one
+``torch.autograd.Function``.
+
+* forward ``y = x w^T + b``      -> ``ops.conv.linear_bf16`` (the persistent MFMA GEMM for large layers);
+* data gradient ``dx = dy w``    -> the same kernel with the transposed weight as its "weight" operand;
+* weight gradient ``dw = dy^T x`` -> ``csrc/kernels/conv_wgrad.hip`` as a 1 x 1 convolution: its output is small
+  (N x K) and its reduction runs over every row of the batch, which is what that split-K kernel is built for (a
+  plain output-tiled GEMM would put a 2048 x 512 gradient on 16 workgroups with a 32 768-deep reduction each);
+* bias gradient = a column sum.
+
+Layers the kernels do not take (feature counts that are not multiples of 64 after padding, CPU tensors) fall back to
+PyTorch.  The reference has no training code; there is nothing to cite.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import conv as C
+from .conv_train import conv_wgrad
+
+
+def _pad_to(t: torch.Tensor, dim: int, mult: int) -> torch.Tensor:
+    n = t.shape[dim]
+    p = (-n) % mult
+    if p == 0:
+        return t
+    pad = [0, 0] * (t.dim() - 1 - dim) + [0, p]
+    return F.pad(t, pad)
+
+
+class _LinearBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]):
+        # x: [M, K] bf16 contiguous; weight: [N, K] (the nn.Linear parameter, any float dtype); bias: [N] or None
+        w = weight.detach().to(torch.bfloat16).contiguous()
+        b = None if bias is None else bias.detach().float().contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.meta = (weight.dtype, None if bias is None else bias.dtype)
+        return C.linear_bf16(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy: torch.Tensor):
+        x, w = ctx.saved_tensors
+        wdtype, bdtype = ctx.meta
+        dy = dy.to(torch.bfloat16).contiguous()
+        M, K = x.shape
+        N = w.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = C.linear_bf16(dy, w.t().contiguous())
+        if ctx.needs_input_grad[1]:
+            # 1 x 1 "convolution" over M pixels; the kernel wants both channel counts in multiples of 64
+            xp, dyp = _pad_to(x, 1, 64), _pad_to(dy, 1, 64)
+            dwp = conv_wgrad(xp.view(1, M, 1, xp.shape[1]), dyp.view(1, M, 1, dyp.shape[1]), 1, 1, (1, 1), (0, 0))
+            dw = dwp.view(dyp.shape[1], xp.shape[1])[:N, :K].to(wdtype)
+        if bdtype is not None and ctx.needs_input_grad[2]:
+            db = dy.sum(0, dtype=torch.float32).to(bdtype)
+        return dx, dw, db
+
+
+def linear_train(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Differentiable ``x @ weight^T + bias`` in bf16.  x: [..., K]; returns [..., N] bf16."""
+    lead = x.shape[:-1]
+    K = x.shape[-1]
+    if not x.is_cuda or K % 8 != 0:
+        return F.linear(x.to(weight.dtype), weight, bias).to(torch.bfloat16 if x.is_cuda else x.dtype)
+    y = _LinearBF16.apply(x.reshape(-1, K).to(torch.bfloat16).contiguous(), weight, bias)
+    return y.reshape(*lead, weight.shape[0])

@@ -1,9 +1,10 @@
 """Differentiable bidirectional LSTM layer on the persistent HIP kernels (csrc/kernels/lstm_train.hip).
 
-Training-side twin of ``ops/lstm.py``: the input projection (and its gradients, and the W_hh gradient) are
-large library GEMMs through autograd; only the two recurrences - forward over the steps, backward over
-them in reverse - run in the hand-written kernels, one launch each instead of one GEMM + one cell kernel per
-time step (the eager path needs ~10 000 launches per CRNN training step; ``profiles/15``).
+Training-side twin of ``ops/lstm.py``: the input projection and its gradients run on the in-repo GEMM and
+weight-gradient kernels (``ops/linear_train.py``); the two recurrences - forward over the steps, backward over them
+in reverse - run in the hand-written persistent kernels, one launch each instead of one GEMM + one cell kernel per
+time step (the eager path needs ~10 000 launches per CRNN training step); the W_hh gradient is one GEMM per
+direction over all steps.
 
 Semantics are those of ``nn.LSTM(bidirectional=True, batch_first=True)`` fed a packed sequence and padded
 back: steps at ``t >= len`` output zeros and receive no gradient; the reverse direction starts at ``len-1``.
@@ -90,7 +91,10 @@ def bilstm_train(x: torch.Tensor, m: torch.nn.LSTM, lens: Optional[torch.Tensor]
     w_ih = torch.cat([m.weight_ih_l0[perm], m.weight_ih_l0_reverse[perm]], 0)
     b = torch.cat([(m.bias_ih_l0 + m.bias_hh_l0)[perm], (m.bias_ih_l0_reverse + m.bias_hh_l0_reverse)[perm]], 0)
     w_hh = torch.stack([m.weight_hh_l0[perm], m.weight_hh_l0_reverse[perm]], 0)
-    xproj = F.linear(x.to(torch.bfloat16), w_ih.to(torch.bfloat16), b.to(torch.bfloat16)).contiguous()
+    # the input projection and both of its gradients on the in-repo GEMM / weight-gradient kernels (ops/linear_train.py)
+    from .linear_train import linear_train
+
+    xproj = linear_train(x, w_ih, b).contiguous()
     if lens is not None:
         lens = lens.to(x.device, torch.int32)
     return _BiLSTMRecurrence.apply(xproj, w_hh, lens)

@@ -97,6 +97,8 @@ def lib() -> ctypes.CDLL:
             l.dlpdf_image_decode.argtypes = [vp, i, i, vp, sz]
             l.dlpdf_image_decode.restype = ctypes.c_longlong
             l.dlpdf_classify.argtypes = [vp, ctypes.POINTER(_Classify)]
+            l.dlpdf_fast_inflate.argtypes = [vp, sz, vp, sz]
+            l.dlpdf_fast_inflate.restype = ctypes.c_longlong
             l.dljpeg_sizes.argtypes = [ctypes.POINTER(i), ctypes.POINTER(i)]
             l.dljpeg_scan.argtypes = [vp, sz, ctypes.POINTER(JpegInfo), vp, vp, i]
             l.dljpeg_decode_sync_host.argtypes = [vp, sz, vp, sz, ctypes.POINTER(JpegSyncStats)]
@@ -208,6 +210,15 @@ def decode_jpeg_sync_host(data) -> Tuple[np.ndarray, JpegSyncStats]:
     if rc != 0:
         raise PdfError(f"self-synchronising decode failed (code {rc})")
     return out[: i.height, : i.width], stats
+
+
+def fast_inflate(data, capacity: int) -> Optional[np.ndarray]:
+    """The library's own zlib-stream decoder (csrc/pdf/fast_inflate.h) on ``data``: the inflated bytes, or None when
+    it refuses the stream (damaged, truncated, larger than ``capacity``) - inside the library zlib then takes over."""
+    src = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    out = np.empty(max(1, int(capacity)), dtype=np.uint8)
+    n = lib().dlpdf_fast_inflate(src.ctypes.data, src.size, out.ctypes.data, int(capacity))
+    return None if n < 0 else out[:n]
 
 
 class PdfDocument:

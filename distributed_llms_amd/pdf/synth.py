@@ -602,10 +602,44 @@ def encode_page_ccitt_g4(page: np.ndarray, threshold: int = 128) -> Tuple[bytes,
     return raw[offs[0] : offs[0] + cnts[0]], int(t.tag_v2.get(262, 0)) == 1
 
 
+def png_predict_rows(page: np.ndarray, row_filter: Optional[int] = None) -> bytes:
+    """Rows of ``page`` (uint8 [H, W] or [H, W, 3]) with PNG predictors applied, each prefixed by its filter-type
+    byte (PDF ``/Predictor 15``).  ``row_filter``: 0 None, 1 Sub, 2 Up, 3 Average, 4 Paeth; default: row y uses y % 5."""
+    H = page.shape[0]
+    bpp = 1 if page.ndim == 2 else page.shape[2]
+    flat = page.reshape(H, -1).astype(np.int32)
+    out = bytearray()
+    prev = np.zeros(flat.shape[1], np.int32)
+    zero = np.zeros(bpp, np.int32)
+    for y in range(H):
+        cur = flat[y]
+        a = np.concatenate([zero, cur[:-bpp]])
+        ft = y % 5 if row_filter is None else row_filter
+        if ft == 0:
+            enc = cur
+        elif ft == 1:
+            enc = cur - a
+        elif ft == 2:
+            enc = cur - prev
+        elif ft == 3:
+            enc = cur - ((a + prev) >> 1)
+        else:
+            c = np.concatenate([zero, prev[:-bpp]])
+            p = a + prev - c
+            pa, pb, pc = np.abs(p - a), np.abs(p - prev), np.abs(p - c)
+            enc = cur - np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+        out.append(ft)
+        out += (enc & 255).astype(np.uint8).tobytes()
+        prev = cur
+    return bytes(out)
+
+
 def make_scanned_pdf(pages: Sequence[np.ndarray], codec: str = "jpeg", quality: int = 85, dpi: int = 300,
                      restart_blocks: int = 62, xref_stream: bool = False,
-                     encoded: Optional[Sequence[bytes]] = None, rotate: int = 0) -> bytes:
+                     encoded: Optional[Sequence[bytes]] = None, rotate: int = 0, predictor: int = 1,
+                     encoded_ccitt: Optional[Sequence[Tuple[bytes, bool]]] = None) -> bytes:
     """PDF with one full-page image per page.  ``pages``: uint8 [H, W] (gray) or [H, W, 3] arrays.
+    ``predictor`` (codec "flate"): 1 none; 10-15: rows are PNG-predicted before compression, as image tools write them.
 
     ``encoded`` may carry pre-encoded image streams (same order) to avoid re-encoding.
     ``rotate`` (0/90/180/270): what a scanner's "landscape feed" produces - the stored raster is turned
@@ -625,11 +659,19 @@ def make_scanned_pdf(pages: Sequence[np.ndarray], codec: str = "jpeg", quality: 
             data = encoded[i] if encoded is not None else encode_page_jpeg(pg, quality, restart_blocks)
             flt = b"/DCTDecode"
         elif codec == "flate":
-            data = encoded[i] if encoded is not None else zlib.compress(np.ascontiguousarray(pg).tobytes(), 1)
+            if encoded is not None:
+                data = encoded[i]
+            elif predictor >= 10:
+                data = zlib.compress(png_predict_rows(pg, None if predictor == 15 else predictor - 10), 1)
+            else:
+                data = zlib.compress(np.ascontiguousarray(pg).tobytes(), 1)
             flt = b"/FlateDecode"
+            if predictor >= 10:
+                flt += b" /DecodeParms << /Predictor %d /Colors %d /BitsPerComponent 8 /Columns %d >>" % (
+                    predictor, 1 if pg.ndim == 2 else 3, W)
         elif codec == "ccitt":
             # bilevel Group 4 fax data, what office scanners emit for black-and-white scans
-            data, black_is_1 = encode_page_ccitt_g4(pg)
+            data, black_is_1 = encoded_ccitt[i] if encoded_ccitt is not None else encode_page_ccitt_g4(pg)
             img = w.add(w.stream(
                 b"/Type /XObject /Subtype /Image /Width %d /Height %d /ColorSpace /DeviceGray /BitsPerComponent 1 "
                 b"/Filter /CCITTFaxDecode /DecodeParms << /K -1 /Columns %d /Rows %d /BlackIs1 %s >>"

@@ -49,6 +49,7 @@ class DocumentResult:
     error: Optional[str] = None                 # set instead of content when the document could not be read
     language: str = "und"                       # utils/langid.detect over the combined text ("und": too little text)
     language_confidence: float = 0.0
+    warnings: List[str] = field(default_factory=list)   # pages that could not be read completely (damaged image streams)
 
 
 _MD_HEADER = re.compile(r"#+\s+")
@@ -168,6 +169,7 @@ def assemble_document(document_id: str, mode: str, pages: Sequence[PageResult], 
     image writer here (``LocalFileWriter.write(path, data)``, ocr_service.py:111-124, 216)."""
     res = DocumentResult(document_id, mode)
     res.pages = sorted(pages, key=lambda p: p.page_index)
+    res.warnings = [f"page {p.page_index + 1}: {p.error}" for p in res.pages if getattr(p, "error", None)]
     if image_writer is not None:
         write_figures(res.pages, document_id, image_writer)
     res.content_list = build_content_list(res.pages)
@@ -232,6 +234,9 @@ def assemble_packed(document_id: str, mode: str, shards: Sequence, extra: Dict[i
                 content.append(it)
             continue
         sh, k = hit
+        err = sh.page_error(k)
+        if err:
+            res.warnings.append(f"page {i + 1}: {err}")
         paths: Dict[int, str] = {}
         f0 = int(sh.fig_off[k])
         for f in range(f0, int(sh.fig_off[k + 1])):

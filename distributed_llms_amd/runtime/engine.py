@@ -100,6 +100,7 @@ class PageResult:
     figures: List[Figure] = field(default_factory=list)
     n_detected: int = 0          # boxes the detector itself produced
     used_layout_prior: bool = False
+    error: Optional[str] = None  # the page image could not be decoded completely: no text is reported for it
 
     def text(self) -> str:
         return "\n".join(l.text for l in self.lines if l.text)
@@ -156,7 +157,7 @@ class StageTimer:
 
 class _DetBatch:
     __slots__ = ("pages", "srcs", "boxes_host", "nbox_host", "fig_host", "nfig_host", "frm_host", "nfrm_host", "event", "stream",
-                 "slot", "keep")
+                 "slot", "keep", "jpeg_counts", "jpeg_rows", "page_errors")
 
 
 class _RecBatch:
@@ -248,6 +249,7 @@ class OcrEngine:
         db.pages = list(pages)
         db.stream = st
         db.slot = slot
+        db.jpeg_counts, db.jpeg_rows, db.page_errors = None, [], {}
         B = len(pages)
         geo = [self.det_geometry(*p.hw) for p in pages]
         Hd = max(g[2] for g in geo)
@@ -264,6 +266,12 @@ class OcrEngine:
                     dec = [torch.from_numpy(_to_gray(jpeg_ops.decode_jpeg_host(pages[i].encoded[0]))) for i in enc]
                 for i, t in zip(enc, dec):
                     srcs[i] = t
+                if self.on_gpu:
+                    # how many blocks each restart-less stream really decoded: read with the boxes, compared in _det_boxes
+                    counted, db.jpeg_rows = jpeg_ops.blocks_short(srcs)
+                    if counted is not None:
+                        db.jpeg_counts = torch.empty(counted.shape, dtype=torch.int32, pin_memory=True)
+                        db.jpeg_counts.copy_(counted, non_blocking=True)
             regions = []
             for i, (p, (oh, ow, _, _)) in enumerate(zip(pages, geo)):
                 img = srcs[i]
@@ -376,6 +384,12 @@ class OcrEngine:
         frms = None
         if db.event is not None:
             db.event.synchronize()
+            if db.jpeg_counts is not None:
+                got = db.jpeg_counts.numpy()
+                for pos, row, want in db.jpeg_rows:
+                    if int(got[row]) != want:
+                        db.page_errors[pos] = (f"page image is damaged: {int(got[row])} of {want} JPEG blocks could be decoded; "
+                                               "no text is reported for this page")
             nb = db.nbox_host.numpy()
             bx = db.boxes_host.numpy()
             res = [bx[b, : min(int(nb[b]), cfg.db.max_boxes)].copy() for b in range(len(db.pages))]
@@ -392,6 +406,10 @@ class OcrEngine:
             frms = None if db.frm_host is None else [np.asarray(f, np.float32).reshape(-1, 8)[:, :5] for f in db.frm_host]
         out = []
         for pi, (r, p) in enumerate(zip(res, db.pages)):
+            if pi in db.page_errors:
+                # what the detector saw is noise from the point where the stream broke: report nothing rather than garbage
+                out.append((np.zeros((0, 8), np.float32), np.zeros((0, 5), np.float32)))
+                continue
             r = np.asarray(r, dtype=np.float32)
             r = r.reshape(-1, r.shape[1] if r.ndim == 2 and r.shape[1] else 8)
             if r.shape[1] < 8:
@@ -477,7 +495,7 @@ class OcrEngine:
             b5 = bx[:, [0, 1, 2, 3, 6]] if n_det else np.zeros((0, 5), np.float32)
             blk = bx[:, 5].astype(np.int32) if n_det else np.zeros((0,), np.int32)
             knd = bx[:, 7].astype(np.int32) if n_det and bx.shape[1] > 7 else np.zeros((b5.shape[0],), np.int32)
-            if p.layout_prior is not None and not self._detections_usable(bx, p):
+            if p.layout_prior is not None and pi not in db.page_errors and not self._detections_usable(bx, p):
                 b4 = np.asarray(p.layout_prior, dtype=np.float32).reshape(-1, 4)
                 order, blk, _ = layout.order_page_native(b4, float(p.hw[0]))
                 b5 = np.concatenate([b4[order], np.zeros((b4.shape[0], 1), np.float32)], 1)
@@ -798,7 +816,7 @@ class OcrEngine:
         pos = 0
         for pi, (p, (n_det, used_prior, b4, blk, fg, knd)) in enumerate(zip(rb.det.pages, per_page)):
             r = PageResult(p.doc_id, p.page_index, p.hw[1], p.hw[0],
-                           n_detected=n_det, used_layout_prior=used_prior)
+                           n_detected=n_det, used_layout_prior=used_prior, error=rb.det.page_errors.get(pi))
             for k in range(b4.shape[0]):
                 gi = pos + k
                 if knd[k] == 1:

@@ -34,7 +34,12 @@ class Extractor:
         """Reference-shaped result dict; never raises (ocr_service.py:250-255)."""
         try:
             doc = self.extract_document(pdf_bytes, document_id)
-            return {"status": "completed", "result": doc.text, "mode": doc.mode, "pages": len(doc.pages)}
+            out = {"status": "completed", "result": doc.text, "mode": doc.mode, "pages": len(doc.pages)}
+            if doc.warnings:
+                # pages whose image stream was damaged are reported, not silently read as noise
+                logger.warning(f"{document_id}: " + "; ".join(doc.warnings[:8]))
+                out["warnings"] = list(doc.warnings)
+            return out
         except Exception as e:  # noqa: BLE001 - every failure becomes a 'failed' status
             logger.error(f"Error processing PDF {document_id}: {e}")
             return {"status": "failed", "error": str(e)}

@@ -60,8 +60,10 @@ def pack_shard(pages: Sequence[Tuple[int, Optional[object]]], items_of=None) -> 
     f_box: List[Tuple[float, float, float, float]] = []
     f_order: List[int] = []
     f_png: List[bytes] = []
+    errs: List[str] = []
     for k, (i, pr) in enumerate(pages):
         idx[k] = i
+        errs.append((getattr(pr, "error", None) or "") if pr is not None else "")
         if pr is not None:
             meta[k] = (pr.width, pr.height, pr.n_detected, int(pr.used_layout_prior), 1)
             for ln in pr.lines:
@@ -105,6 +107,7 @@ def pack_shard(pages: Sequence[Tuple[int, Optional[object]]], items_of=None) -> 
         "i_text": "".join(i_texts).encode("utf-8", "surrogatepass"),
         "f_box": np.asarray(f_box, np.float32).reshape(-1, 4), "f_order": np.asarray(f_order, np.int32),
         "png_off": png_off, "png": b"".join(f_png),
+        "err_off": offsets(errs), "err": "".join(errs).encode("utf-8", "surrogatepass"),
     }
     head: Dict[str, list] = {}
     blobs: List[bytes] = []
@@ -176,6 +179,13 @@ class PackedShard:
             self._itext = bytes(self._sec["i_text"]).decode("utf-8", "surrogatepass")
         return self._itext
 
+    def page_error(self, k: int) -> Optional[str]:
+        """Why page slot ``k`` carries no text although it had an image (a damaged image stream), or None."""
+        a, b = int(self.err_off[k]), int(self.err_off[k + 1])
+        if a == b:
+            return None
+        return bytes(self._sec["err"]).decode("utf-8", "surrogatepass")[a:b]
+
     def figure_png(self, f: int) -> bytes:
         o = self.png_off
         return bytes(self._sec["png"][int(o[f]) : int(o[f + 1])])
@@ -208,7 +218,7 @@ class PackedShard:
         if not self.present(k):
             return None
         w, h, nd, up, _ = (int(v) for v in self.meta[k])
-        pr = PageResult(doc_id, int(self.idx[k]), w, h, n_detected=nd, used_layout_prior=bool(up))
+        pr = PageResult(doc_id, int(self.idx[k]), w, h, n_detected=nd, used_layout_prior=bool(up), error=self.page_error(k))
         t, off = self._t(), self.text_off
         bx, cf, bl, an, kd = self.boxes, self.conf, self.block, self.angle, self.kind
         for j in range(int(self.line_off[k]), int(self.line_off[k + 1])):

@@ -53,7 +53,7 @@ HIP_FLAGS = [
     # some of their encodings have produced silently wrong values on this hardware pool
     "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
 ]
-CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-pthread"]
+CXX_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-pthread"]
 
 
 class BuildError(RuntimeError):

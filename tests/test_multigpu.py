@@ -96,14 +96,13 @@ def _torchrun(script, nproc, *flags, timeout=900):
 @pytest.mark.parametrize("mb", [1, 20, 64, 668])
 def test_allreduce_bench_direct_against_rccl(mb):
     """Direct (all-links) kernel against RCCL for a 1 MB latency-bound call, a CRNN-sized gradient (20 MB), one
-    bucket (64 MB) and a TrOCR-base-sized gradient (668 MB); the numbers land in the JSON line, the test only checks
-    that both paths ran and agree."""
+    bucket (64 MB) and a TrOCR-base-sized gradient (668 MB); the numbers land in the JSON line (per algorithm: time and
+    bus bandwidth), the test only checks that every path ran - their results are compared by the oracle tests above."""
     n = min(N_GPUS, 8)
     out = _torchrun("bench/allreduce_bench.py", n, "--gpus", str(n), "--steps", "10", "--warmup", "3", "--mb", str(mb))
     assert len(out) == 1 and out[0]["n_gpus"] == n and out[0]["value"] > 0
-    cfg = out[0]["config"]
-    assert cfg.get("direct_us") and cfg.get("rccl_us"), cfg
-    assert cfg.get("max_abs_diff", 0.0) <= cfg.get("tolerance", 1e-2)
+    per = out[0]["config"]["ms_per_algorithm"]
+    assert {"rccl", "direct_two_shot", "direct_in_place"} <= set(per) and all(v > 0 for v in per.values()), per
 
 
 def test_bench_scales_over_devices():

@@ -352,3 +352,46 @@ def test_jpeg_routing_by_restart_structure():
     c = reader.scan_jpeg(_jpeg_bytes(img, quality=80, restart_marker_rows=40))      # 6 long segments: host
     d = reader.scan_jpeg(_jpeg_bytes(img, quality=80, progressive=True))
     assert (a.info.supported, b.info.supported, c.info.supported, d.info.supported) == (2, 1, 0, 0)
+
+
+def test_in_repo_inflater_matches_zlib_and_refuses_what_it_cannot_finish():
+    """csrc/pdf/fast_inflate.h: exact round trips over stored / fixed / dynamic blocks, run-length and Huffman-only
+    streams and sizes around the fast loop's margins; a stream that is cut short or does not fit the buffer is refused
+    (the library then falls back to zlib), never decoded past the buffer."""
+    import zlib
+
+    rng = np.random.default_rng(0)
+    page = np.ascontiguousarray(synth.render_page(3, size=(620, 877), font_px=14, margin=40)[0]).tobytes()
+    cases = [b"", b"a", b"abc" * 1000, bytes(rng.integers(0, 256, 100000, dtype=np.uint8)), b"\0" * 300000,
+             bytes(rng.integers(0, 4, 200000, dtype=np.uint8)), page]
+    cases += [bytes(rng.integers(0, 256, n, dtype=np.uint8)) for n in (7, 8, 9, 16, 17, 319, 320, 321, 400)]
+    for raw in cases:
+        for level in (0, 1, 6, 9):
+            for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED):
+                c = zlib.compressobj(level, zlib.DEFLATED, 15, 9, strategy)
+                z = c.compress(raw) + c.flush()
+                for cap in (len(raw), len(raw) + 5, len(raw) + 4096):
+                    got = reader.fast_inflate(z, cap)
+                    assert got is not None and bytes(got) == raw, (len(raw), level, strategy, cap)
+                if raw:
+                    assert reader.fast_inflate(z, len(raw) - 1) is None
+    z = zlib.compress(page, 6)
+    for cut in (1, 2, 5, 100, len(z) // 2, len(z) - 5):
+        got = reader.fast_inflate(z[:cut], len(page))
+        assert got is None or bytes(got) == page[: len(got)]
+    assert reader.fast_inflate(b"\x78\x9d" + z[2:], len(page)) is None            # header check bits do not add up
+    assert reader.fast_inflate(b"\x78\xbb" + z[2:], len(page)) is None            # preset dictionary: not ours
+
+
+def test_flate_scan_with_png_predictors_decodes_like_the_plain_one():
+    """A Flate image whose rows carry PNG predictor bytes (what image tools write) gives the same raster as the
+    unpredicted stream: the plain stream is inflated straight into the caller's buffer, the predicted one goes through
+    the filter chain.  Gray and RGB, every predictor type."""
+    gray = synth.render_page(5, size=(310, 438), font_px=12, margin=16)[0]
+    rgb = np.stack([gray, 255 - gray, (gray.astype(np.int32) * 3 // 4).astype(np.uint8)], -1)
+    for page in (gray, rgb):
+        for predictor in (1, 11, 12, 13, 14, 15):
+            doc = reader.PdfDocument(synth.make_scanned_pdf([page], codec="flate", dpi=40, predictor=predictor))
+            got = doc.decode_image(doc.main_image(0))
+            assert np.array_equal(got, page), (page.ndim, predictor)
+            doc.close()
