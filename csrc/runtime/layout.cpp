@@ -23,6 +23,7 @@ struct Cutter {
   int min_col_lines;
   std::vector<int> order;
   std::vector<int> block_of;
+  std::vector<char> table_block;   // per leaf: its boxes are the cells of a table, in row-major order
   int n_blocks = 0;
 
   Cutter(const std::vector<Box>& boxes, double col_gap, double block_gap, int mcl, double ta)
@@ -69,7 +70,62 @@ struct Cutter {
     return out;
   }
 
-  void leaf(const std::vector<int>& idx) {
+  // Rows of a region: boxes whose vertical centres lie within half a line height of the row's first box, each row
+  // left to right (the order ``leaf`` emits).
+  std::vector<std::vector<int>> rows_of(const std::vector<int>& idx) const {
+    std::vector<int> o(idx);
+    auto cy = [&](int i) { return 0.5 * (b[i].y0 + b[i].y1); };
+    std::stable_sort(o.begin(), o.end(), [&](int p, int q) { return cy(p) < cy(q); });
+    std::vector<std::vector<int>> rows;
+    size_t start = 0;
+    for (size_t i = 1; i <= o.size(); ++i) {
+      if (i == o.size() || cy(o[i]) - cy(o[start]) > 0.5 * h_med) {
+        std::vector<int> r(o.begin() + start, o.begin() + i);
+        std::stable_sort(r.begin(), r.end(), [&](int p, int q) { return b[p].x0 < b[q].x0; });
+        rows.push_back(std::move(r));
+        start = i;
+      }
+    }
+    return rows;
+  }
+
+  // A region is a table when its boxes form a grid: at least ``min_rows`` rows of two or more cells each, the cells
+  // of all rows falling into common columns (the whitespace between the columns runs through every row, at least a
+  // line height wide), no row with two cells in one column, every column filled in at least half of the rows, and at
+  // most one column of long text (two columns of running text whose lines happen to share baselines are not a table).
+  bool is_table(const std::vector<int>& idx, int min_rows) const {
+    if ((int)idx.size() < 2 * min_rows) return false;
+    for (int i : idx) if (b[i].y1 - b[i].y0 > 3.0 * h_med) return false;     // a figure or a rotated line: no cell
+    auto rows = rows_of(idx);
+    if ((int)rows.size() < min_rows) return false;
+    for (auto& r : rows) if (r.size() < 2) return false;
+    std::vector<double> cuts;
+    for (auto& g : gaps<false>(idx)) if (g.width >= h_med) cuts.push_back(0.5 * (g.start + g.end));
+    if (cuts.empty()) return false;
+    std::sort(cuts.begin(), cuts.end());
+    const size_t C = cuts.size() + 1;
+    std::vector<int> filled(C, 0);
+    std::vector<std::vector<double>> aspect(C);
+    for (auto& r : rows) {
+      std::vector<char> seen(C, 0);
+      for (int i : r) {
+        const size_t c = std::lower_bound(cuts.begin(), cuts.end(), b[i].x0 + 1e-6) - cuts.begin();
+        if (seen[c]) return false;
+        seen[c] = 1;
+        ++filled[c];
+        aspect[c].push_back((b[i].x1 - b[i].x0) / std::max(b[i].y1 - b[i].y0, 1.0));
+      }
+    }
+    int wide = 0;
+    for (size_t c = 0; c < C; ++c) {
+      if (2 * filled[c] < (int)rows.size()) return false;
+      if (median(aspect[c]) >= 10.0) ++wide;
+    }
+    return wide <= 1;
+  }
+
+  void leaf(const std::vector<int>& idx, bool table = false) {
+    table_block.push_back(table ? 1 : 0);
     std::vector<int> o(idx);
     auto cy = [&](int i) { return 0.5 * (b[i].y0 + b[i].y1); };
     std::stable_sort(o.begin(), o.end(), [&](int p, int q) { return cy(p) < cy(q); });
@@ -104,6 +160,8 @@ struct Cutter {
   void cut(const std::vector<int>& idx, int depth) {
     if (idx.empty()) return;
     if (idx.size() == 1 || depth > 12) { leaf(idx); return; }
+    // 0. a grid of cells is read row by row, whatever its columns look like
+    if (is_table(idx, 3)) { leaf(idx, true); return; }
     auto cuts = column_cuts(idx);
     if (!cuts.empty()) {
       for (auto& part : split_at<false>(idx, cuts)) cut(part, depth + 1);
@@ -118,6 +176,21 @@ struct Cutter {
         while (i < parts.size()) {
           size_t j = i;
           std::vector<int> merged(parts[i]);
+          // the rows of a table whose row spacing is as large as a block gap belong together
+          while (j + 1 < parts.size()) {
+            std::vector<int> trial(merged);
+            trial.insert(trial.end(), parts[j + 1].begin(), parts[j + 1].end());
+            if (!is_table(trial, 2)) break;
+            merged.swap(trial);
+            ++j;
+          }
+          if (j > i && is_table(merged, 3)) {
+            leaf(merged, true);
+            i = j + 1;
+            continue;
+          }
+          j = i;
+          merged = parts[i];
           while (j + 1 < parts.size()) {
             std::vector<int> trial(merged);
             trial.insert(trial.end(), parts[j + 1].begin(), parts[j + 1].end());
@@ -154,9 +227,11 @@ struct Cutter {
   }
 };
 
-void reading_order(const std::vector<Box>& boxes, std::vector<int>* order, std::vector<int>* block) {
+void reading_order(const std::vector<Box>& boxes, std::vector<int>* order, std::vector<int>* block,
+                   std::vector<char>* in_table = nullptr) {
   order->clear();
   block->assign(boxes.size(), 0);
+  if (in_table) in_table->assign(boxes.size(), 0);
   if (boxes.empty()) return;
   Cutter c(boxes, 1.2, 0.9, 3, 4.0);
   std::vector<int> all(boxes.size());
@@ -164,6 +239,8 @@ void reading_order(const std::vector<Box>& boxes, std::vector<int>* order, std::
   c.cut(all, 0);
   *order = c.order;
   *block = c.block_of;
+  if (in_table)
+    for (size_t i = 0; i < boxes.size(); ++i) (*in_table)[i] = c.table_block[c.block_of[i]];
 }
 
 }  // namespace
@@ -171,7 +248,8 @@ void reading_order(const std::vector<Box>& boxes, std::vector<int>* order, std::
 extern "C" {
 
 // boxes [n][4], figures [nf][4] (x0, y0, x1, y1, y down).  Writes n + nf entries each of order_out (indices into
-// [boxes ; figures]), block_out and kind_out (0 text line, 1 figure), aligned with order_out.  Returns n + nf.
+// [boxes ; figures]), block_out and kind_out (0 text line, 1 figure, 2 cell of a table: the cells of one table share a
+// block and come row by row), aligned with order_out.  Returns n + nf.
 int dlrt_layout_order(const float* boxes, int n, const float* figs, int nf, float page_h, int* order_out, int* block_out,
                       int* kind_out) {
   if (n < 0 || nf < 0) return -1;
@@ -230,13 +308,14 @@ int dlrt_layout_order(const float* boxes, int n, const float* figs, int nf, floa
     std::vector<Box> g;
     for (int i : body) g.push_back(bx[i]);
     for (int i = 0; i < nf; ++i) g.push_back({figs[4 * i], figs[4 * i + 1], figs[4 * i + 2], figs[4 * i + 3]});
-    reading_order(g, &o, &blk);
+    std::vector<char> in_table;
+    reading_order(g, &o, &blk, &in_table);
     int mx = -1;
     for (int i : o) {
       const bool fig = i >= (int)body.size();
       order_out[k] = fig ? n + (i - (int)body.size()) : body[i];
       block_out[k] = nblk + blk[i];
-      kind_out[k] = fig ? 1 : 0;
+      kind_out[k] = fig ? 1 : (in_table[i] ? 2 : 0);
       mx = std::max(mx, blk[i]);
       ++k;
     }

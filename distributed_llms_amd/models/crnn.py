@@ -27,6 +27,7 @@ import torch.nn as nn
 from ..ops import ctc as ctc_ops
 from ..ops import lstm as lstm_ops
 from ..ops.conv import linear_bf16
+from ..utils.scripts import CYRILLIC_EXTRA, GREEK_EXTRA, resolve_scripts, to_visual
 from .layers import ConvBNAct, prepare_all
 
 # 95 printable ASCII characters; vocabulary index 0 is the CTC blank.
@@ -35,6 +36,9 @@ ASCII_CHARSET = "".join(chr(c) for c in range(32, 127))
 # FOLLOW the ASCII classes, so a model grown from an ASCII checkpoint keeps its class indices.
 LATIN_EXTRA = ("ÀÁÂÃÄÅÆÇÈÉÊËÌÍÎÏÑÒÓÔÕÖØÙÚÛÜÝ" "àáâãäåæçèéêëìíîïñòóôõöøùúûüýÿß" "Œœ€£§°«»¿¡")
 DEFAULT_CHARSET = ASCII_CHARSET + LATIN_EXTRA
+# Cyrillic and Greek letters that no Latin letter looks like follow in turn (utils/scripts.py: letters that share a
+# shape across the alphabets share the Latin class, and the decoded line is resolved back to code points by word).
+MULTI_CHARSET = DEFAULT_CHARSET + CYRILLIC_EXTRA + GREEK_EXTRA
 
 
 class CRNN(nn.Module):
@@ -86,11 +90,12 @@ class CRNN(nn.Module):
         self._packed = None
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
-        """A checkpoint with fewer (or more) classes than this model reads the leading part of ``DEFAULT_CHARSET``:
-        the model takes the checkpoint's character set (weights trained on printable ASCII have 96 classifier rows)."""
+        """A checkpoint with fewer (or more) classes than this model reads the leading part of ``MULTI_CHARSET``:
+        the model takes the checkpoint's character set (weights trained on printable ASCII have 96 classifier rows,
+        on the Western European set 164, with Cyrillic and Greek 258)."""
         w = state_dict.get("fc.weight")
-        if w is not None and w.shape[0] != self.fc.out_features and 1 < w.shape[0] <= len(DEFAULT_CHARSET) + 1:
-            self.set_charset(DEFAULT_CHARSET[: w.shape[0] - 1])
+        if w is not None and w.shape[0] != self.fc.out_features and 1 < w.shape[0] <= len(MULTI_CHARSET) + 1:
+            self.set_charset(MULTI_CHARSET[: w.shape[0] - 1])
         return super().load_state_dict(state_dict, strict=strict, assign=assign)
 
     @staticmethod
@@ -241,12 +246,25 @@ class CRNN(nn.Module):
         logits = linear_bf16(y, fw, fb)
         return ctc_ops.ctc_greedy_decode_ragged(logits, lay.lens, lay.row_off, lay.tmax, blank=0)
 
+    @property
+    def multi_script(self) -> bool:
+        return len(self.charset) > len(DEFAULT_CHARSET)
+
     def decode_strings(self, ids: torch.Tensor, lens: torch.Tensor) -> List[str]:
-        return ctc_ops.ids_to_strings(ids, lens, self.charset)
+        out = ctc_ops.ids_to_strings(ids, lens, self.charset)
+        if self.multi_script:
+            # shape classes -> code points, word by word; ASCII lines return at once
+            out = [s if s.isascii() else resolve_scripts(s) for s in out]
+        return out
 
     def encode_text(self, text: str) -> List[int]:
-        idx = {c: i + 1 for i, c in enumerate(self.charset)}
-        return [idx[c] for c in text if c in idx]
+        idx = self.__dict__.get("_class_of")
+        if idx is None or idx[0] is not self.charset:
+            idx = (self.charset, {c: i + 1 for i, c in enumerate(self.charset)})
+            self.__dict__["_class_of"] = idx
+        if self.multi_script:
+            text = to_visual(text)
+        return [idx[1][c] for c in text if c in idx[1]]
 
     def flops_per_crop(self, W: int) -> float:
         def conv(cin, cout, kh, kw, h, w):

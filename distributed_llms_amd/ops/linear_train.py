@@ -39,6 +39,11 @@ class _LinearBF16(torch.autograd.Function):
         b = None if bias is None else bias.detach().float().contiguous()
         ctx.save_for_backward(x, w)
         ctx.meta = (weight.dtype, None if bias is None else bias.dtype)
+        N = w.shape[0]
+        if N % 8:
+            # the kernel stores 4 output columns at a time (a 258-class classifier): zero rows fill the last group
+            y = C.linear_bf16(x, _pad_to(w, 0, 8), None if b is None else _pad_to(b, 0, 8))
+            return y[:, :N].contiguous()
         return C.linear_bf16(x, w, b)
 
     @staticmethod
@@ -50,7 +55,8 @@ class _LinearBF16(torch.autograd.Function):
         N = w.shape[0]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = C.linear_bf16(dy, w.t().contiguous())
+            # the GEMM's reduction (here over N) runs in 8-element vectors: zero columns fill a ragged N
+            dx = C.linear_bf16(_pad_to(dy, 1, 8), _pad_to(w.t(), 1, 8).contiguous())
         if ctx.needs_input_grad[1]:
             # 1 x 1 "convolution" over M pixels; the kernel wants both channel counts in multiples of 64
             xp, dyp = _pad_to(x, 1, 64), _pad_to(dy, 1, 64)

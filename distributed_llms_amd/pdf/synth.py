@@ -351,17 +351,22 @@ def render_layout_page(seed: int, size: Tuple[int, int] = A4_300DPI, layout: Opt
                        fonts: Optional[Sequence[str]] = None, font_px: Optional[int] = None, skew: float = 0.0,
                        noise: float = 2.0, blur: float = 0.0, margin: Optional[int] = None,
                        header_footer: Optional[bool] = None, formulas: float = 0.0,
-                       i18n: float = 0.0) -> Tuple[np.ndarray, PageTruth]:
+                       i18n: float = 0.0, script: Optional[str] = None) -> Tuple[np.ndarray, PageTruth]:
     """A synthetic scanned page with a real layout: running header / footer, an optional full-width title, one or
     two columns of paragraphs, optionally a figure with its caption inside a column; one font per page drawn from
     ``fonts``; optional skew (degrees), blur and sensor noise.  ``formulas`` > 0: that share of the paragraph breaks
     carries a centred display formula (``random_formula`` through mathtext).  ``i18n``: probability that the page is
-    written in the Western European vocabulary (accented letters, ß, œ, € ...) mixed with the English one.  The truth lists the lines in READING
+    written in the Western European vocabulary (accented letters, ß, œ, € ...) mixed with the English one.
+    ``script``: ``"cyrillic"`` / ``"greek"`` writes the page in the Russian / Greek vocabulary of ``utils.scripts`` (one
+    word in ten stays English, as in real documents) with a font that has the alphabet.  The truth lists the lines in READING
     order (header, title, first column top to bottom, second column, footer) in the upright frame plus ``angle``."""
     W, H = size
     rng = np.random.default_rng(seed)
     layout = layout or LAYOUTS[int(rng.integers(len(LAYOUTS)))]
     fonts = available_fonts(fonts or TRAIN_FONTS) or ["DejaVuSans.ttf"]
+    if script in ("cyrillic", "greek"):
+        probe = ord("Ж") if script == "cyrillic" else ord("λ")
+        fonts = [n for n in fonts if not n.startswith("cm") and probe in (font_code_points(n) or (probe,))] or ["DejaVuSans.ttf"]
     fname = fonts[int(rng.integers(len(fonts)))]
     scale = W / 2480.0
     px = font_px or int(rng.integers(30, 50) * scale)
@@ -386,6 +391,11 @@ def render_layout_page(seed: int, size: Tuple[int, int] = A4_300DPI, layout: Opt
     vocab = None
     if i18n > 0 and rng.random() < i18n:
         vocab = list(_WORDS_I18N) * 2 + list(_WORDS)          # two thirds Western European words
+    if script in ("cyrillic", "greek"):
+        from ..utils import scripts as _scripts
+
+        own = list(_scripts.WORDS_RU if script == "cyrillic" else _scripts.WORDS_EL)
+        vocab = own * (1 + (9 * len(_WORDS)) // len(own)) + list(_WORDS)
     random_text = lambda r, *a, **k: globals()["random_text"](r, *a, vocabulary=vocab, **k)    # noqa: E731
 
     def put(x: int, y: int, t: str, ff, max_x: int) -> Optional[int]:
@@ -498,6 +508,79 @@ def render_layout_page(seed: int, size: Tuple[int, int] = A4_300DPI, layout: Opt
                       np.asarray(figures, dtype=np.float32).reshape(-1, 4), blocks, float(skew), layout, [fname],
                       np.asarray(fboxes, dtype=np.float32).reshape(-1, 4), ftexts, fpos)
     return arr, truth
+
+
+def render_table_page(seed: int, size: Tuple[int, int] = A4_300DPI, rows: int = 5, cols: int = 3, ruled: bool = True,
+                      row_pitch: float = 1.6, column: bool = False, font_name: str = "DejaVuSans.ttf"
+                      ) -> Tuple[np.ndarray, PageTruth, List[List[str]]]:
+    """A page with two paragraphs and a ``rows`` x ``cols`` table between them (first column labels, the others
+    numbers or short words; optional ruling lines; ``row_pitch`` line heights from row to row).  ``column``: the page
+    has two text columns and the table sits inside the left one.  The truth lists the lines in reading order with the
+    cells row by row; the third value is the grid of cell texts."""
+    W, H = size
+    rng = np.random.default_rng(seed)
+    scale = W / 2480.0
+    px = max(8, int(38 * scale))
+    margin = max(6, int(200 * scale))
+    img = Image.new("L", (W, H), 244)
+    d = ImageDraw.Draw(img)
+    f = named_font(font_name, px)
+    line_h = int(px * 1.55)
+    avg_char = max(1.0, f.getlength("abcdefghij") / 10.0)
+    boxes, texts, blocks = [], [], []
+    blk = [0]
+
+    def put(x, y, t):
+        bb = d.textbbox((x, y), t, font=f)
+        d.text((x, y), t, fill=30, font=f)
+        boxes.append([bb[0] - 3, bb[1] - 3, bb[2] + 3, bb[3] + 3])
+        texts.append(t)
+        blocks.append(blk[0])
+
+    gutter = 4 * px
+    col_w = (W - 2 * margin - gutter) // 2 if column else W - 2 * margin
+    max_chars = max(8, int(col_w / avg_char) - 2)
+
+    def paragraph(x, y, n):
+        for _ in range(n):
+            put(x, y, random_text(rng, max_chars, min_words=2))
+            y += line_h
+        blk[0] += 1
+        return y
+
+    y = paragraph(margin, margin, 4) + line_h
+    grid: List[List[str]] = []
+    cw = col_w // cols
+    y_top = y
+    for r in range(rows):
+        row = []
+        for c in range(cols):
+            if r == 0:
+                t = random_text(rng, 10).title() or "Item"
+            elif c == 0:
+                t = random_text(rng, 12) or "row"
+            else:
+                t = ("%d.%02d" % (int(rng.integers(1, 5000)), int(rng.integers(100)))) if rng.random() < 0.7 else (random_text(rng, 8) or "n/a")
+            t = t[: max(3, int(cw / avg_char) - 3)].strip() or "x"
+            put(margin + c * cw + px // 2, y, t)
+            row.append(t)
+        grid.append(row)
+        if ruled:
+            d.line([margin, y + int(line_h * row_pitch) - px // 3, margin + cols * cw, y + int(line_h * row_pitch) - px // 3], fill=90, width=max(1, px // 16))
+        y += int(line_h * row_pitch)
+    if ruled:
+        for c in range(cols + 1):
+            d.line([margin + c * cw, y_top - px // 3, margin + c * cw, y - px // 3], fill=90, width=max(1, px // 16))
+        d.line([margin, y_top - px // 3, margin + cols * cw, y_top - px // 3], fill=90, width=max(1, px // 16))
+    blk[0] += 1
+    y = paragraph(margin, y + line_h, 4)
+    if column:
+        paragraph(margin + col_w + gutter, margin, 14)
+    arr = np.asarray(img, dtype=np.uint8)
+    nz = rng.normal(0.0, 2.0, size=(H // 4 + 1, W // 4 + 1)).astype(np.float32)
+    arr = np.clip(arr.astype(np.float32) + np.repeat(np.repeat(nz, 4, axis=0), 4, axis=1)[:H, :W], 0, 255).astype(np.uint8)
+    return arr, PageTruth(np.asarray(boxes, dtype=np.float32).reshape(-1, 4), texts, blocks=blocks, layout="table",
+                          font_names=[font_name]), grid
 
 
 def render_line(text: str, height: int = 48, font_px: int = 34, seed: int = 0, pad: int = 6,

@@ -50,6 +50,7 @@ class DocumentResult:
     language: str = "und"                       # utils/langid.detect over the combined text ("und": too little text)
     language_confidence: float = 0.0
     warnings: List[str] = field(default_factory=list)   # pages that could not be read completely (damaged image streams)
+    discarded: List[dict] = field(default_factory=list)  # running headers / footers left out of the content list
 
 
 _MD_HEADER = re.compile(r"#+\s+")
@@ -94,27 +95,126 @@ def lines_to_paragraphs(lines: Sequence[TextLine]) -> List[str]:
     return [" ".join(p) for p in paras]
 
 
-def _line_items(lines: Sequence[TextLine], page_idx: int) -> List[dict]:
+MARGIN_BAND = 0.075          # share of the page height at the top / bottom where running lines live (runtime/layout.py)
+
+
+def table_item(grid: Sequence[Sequence[str]], page_idx: int, bbox: Sequence[float]) -> dict:
+    """Content-list item of a table from its cell texts, row-major.  ``table_body`` is HTML as in magic-pdf's content
+    list; ``text`` (rows on lines, cells separated by " | ") is what the combined text picks up
+    (services/ocr_service/ocr_service.py:229-243 takes every item that has a 'text' key)."""
+    import html
+
+    body = "".join("<tr>" + "".join("<td>%s</td>" % html.escape(c) for c in row) + "</tr>" for row in grid)
+    return {"type": "table", "table_body": "<table>%s</table>" % body, "text": "\n".join(" | ".join(r) for r in grid),
+            "table_caption": [], "table_footnote": [], "page_idx": page_idx, "bbox": [round(float(v), 1) for v in bbox],
+            "cells": [list(r) for r in grid]}
+
+
+def table_grid(cells: Sequence[TextLine]) -> List[List[str]]:
+    """Cells of one table (row by row, left to right, as the layout analysis orders them) -> rows x columns of text.
+    A new row starts where x stops growing; the columns are the connected runs of the cells' x-extents, so a row that
+    lacks a cell gets an empty string in that column."""
+    rows: List[List[TextLine]] = []
+    for c in cells:
+        if rows and c.box[0] > rows[-1][-1].box[0]:
+            rows[-1].append(c)
+        else:
+            rows.append([c])
+    spans = sorted((c.box[0], c.box[2]) for c in cells)
+    cols: List[List[float]] = []
+    for a, b in spans:
+        if cols and a <= cols[-1][1]:
+            cols[-1][1] = max(cols[-1][1], b)
+        else:
+            cols.append([a, b])
+    starts = [c[0] for c in cols]
+    import bisect
+
+    grid = []
+    for r in rows:
+        out = [""] * len(cols)
+        for c in r:
+            k = max(0, bisect.bisect_right(starts, c.box[0] + 1e-6) - 1)
+            out[k] = (out[k] + " " + c.text.strip()).strip()
+        grid.append(out)
+    return grid
+
+
+def _line_items(lines: Sequence[TextLine], page_idx: int, page_h: float = 0.0) -> List[dict]:
     """Text paragraphs, with every display formula as an item of its own between them:
     {'type': 'equation', 'text': '$$ ... $$', 'text_format': 'latex'} (magic-pdf's shape for interline equations; the
-    'text' key is what the combined text picks up, services/ocr_service/ocr_service.py:229-243)."""
+    'text' key is what the combined text picks up, services/ocr_service/ocr_service.py:229-243), every table as one
+    'table' item, and every line that lies in the top / bottom margin band as an item of its own marked
+    ``'margin': 'top' | 'bottom'`` - ``drop_running_lines`` decides over the whole document which of those are running
+    headers / footers."""
     items: List[dict] = []
     run: List[TextLine] = []
+    cells: List[TextLine] = []
 
     def flush():
         for para in lines_to_paragraphs(run):
             items.append({"type": "text", "text": para, "page_idx": page_idx})
         run.clear()
 
+    def flush_table():
+        if cells:
+            bb = (min(c.box[0] for c in cells), min(c.box[1] for c in cells), max(c.box[2] for c in cells),
+                  max(c.box[3] for c in cells))
+            items.append(table_item(table_grid(cells), page_idx, bb))
+            cells.clear()
+
+    top, bot = MARGIN_BAND * page_h, (1.0 - MARGIN_BAND) * page_h
     for ln in lines:
-        if getattr(ln, "kind", "text") == "equation":
+        kind = getattr(ln, "kind", "text")
+        if kind == "cell":
+            flush()
+            if cells and cells[-1].block != ln.block:
+                flush_table()
+            cells.append(ln)
+            continue
+        flush_table()
+        if kind == "equation":
             flush()
             items.append({"type": "equation", "text": ("$$ %s $$" % ln.text) if ln.text else "", "text_format": "latex",
                           "page_idx": page_idx, "bbox": [round(float(v), 1) for v in ln.box]})
+        elif page_h > 0 and (ln.box[3] <= top or ln.box[1] >= bot):
+            flush()
+            if ln.text.strip():
+                items.append({"type": "text", "text": ln.text.strip(), "page_idx": page_idx,
+                              "margin": "top" if ln.box[3] <= top else "bottom"})
         else:
             run.append(ln)
     flush()
+    flush_table()
     return items
+
+
+_DIGITS = re.compile(r"\d+")
+_SPACES = re.compile(r"\s+")
+
+
+def drop_running_lines(content: List[dict], n_pages: int) -> Tuple[List[dict], List[dict]]:
+    """Running headers and footers: a line in the top / bottom margin band whose text - digits aside, so that page
+    numbers count - shows up on three or more pages of the document, or on two when those are at least 40 % of it.
+    magic-pdf's layout model labels such blocks and the reference's content list leaves them out
+    (services/ocr_service/ocr_service.py:215-243); here the label comes from position plus repetition across pages.
+    -> (content without them, the dropped items as {'type': 'header' | 'footer', 'text', 'page_idx'}).  A
+    single-page document keeps everything: one page cannot show what repeats."""
+    where: Dict[Tuple[str, str], set] = {}
+    for it in content:
+        m = it.get("margin")
+        if m:
+            key = (m, _SPACES.sub(" ", _DIGITS.sub("#", it["text"].lower())).strip())
+            where.setdefault(key, set()).add(it["page_idx"])
+    running = {k for k, pages in where.items() if len(pages) >= 3 or (len(pages) >= 2 and len(pages) >= 0.4 * n_pages)}
+    kept, dropped = [], []
+    for it in content:
+        m = it.pop("margin", None)
+        if m and (m, _SPACES.sub(" ", _DIGITS.sub("#", it["text"].lower())).strip()) in running:
+            dropped.append({"type": "header" if m == "top" else "footer", "text": it["text"], "page_idx": it["page_idx"]})
+        else:
+            kept.append(it)
+    return kept, dropped
 
 
 def page_content_items(pg: PageResult) -> List[dict]:
@@ -126,13 +226,20 @@ def page_content_items(pg: PageResult) -> List[dict]:
     pos, li = 0, 0
     for k, fg in figs:
         take = max(0, fg.order - pos)
-        items += _line_items(pg.lines[li : li + take], pg.page_index)
+        items += _line_items(pg.lines[li : li + take], pg.page_index, float(pg.height))
         li += take
         pos += take + 1
         items.append({"type": "image", "img_path": fg.path, "page_idx": pg.page_index,
                       "bbox": [round(float(v), 1) for v in fg.box], "figure": k})
-    items += _line_items(pg.lines[li:], pg.page_index)
+    items += _line_items(pg.lines[li:], pg.page_index, float(pg.height))
     return items
+
+
+def content_markdown(content: Sequence[dict]) -> str:
+    """Markdown of a content list: paragraphs and formulas as they are, figures as image links, tables as HTML (the
+    form magic-pdf writes them in)."""
+    return "\n\n".join(("![](%s)" % it["img_path"]) if it["type"] == "image" else
+                       (it["table_body"] if it["type"] == "table" else it["text"]) for it in content)
 
 
 def build_content_list(pages: Sequence[PageResult]) -> List[dict]:
@@ -156,10 +263,11 @@ def text_layer_page(doc: "reader.PdfDocument", i: int, document_id: str, include
     if not recs:
         return pr
     boxes = np.asarray([r[0] for r in recs], dtype=np.float32).reshape(-1, 4)
-    order, block, _ = layout.order_page_native(boxes, float(pi.height_pt))
+    order, block, kind = layout.order_page_native(boxes, float(pi.height_pt))
     for k, j in enumerate(order):
         box, _size, text = recs[int(j)]
-        pr.lines.append(TextLine(tuple(float(v) for v in box), text, 1.0, int(block[k])))
+        pr.lines.append(TextLine(tuple(float(v) for v in box), text, 1.0, int(block[k]), 0.0,
+                                 "cell" if kind[k] == 2 else "text"))
     return pr
 
 
@@ -172,8 +280,8 @@ def assemble_document(document_id: str, mode: str, pages: Sequence[PageResult], 
     res.warnings = [f"page {p.page_index + 1}: {p.error}" for p in res.pages if getattr(p, "error", None)]
     if image_writer is not None:
         write_figures(res.pages, document_id, image_writer)
-    res.content_list = build_content_list(res.pages)
-    res.markdown = "\n\n".join(("![](%s)" % it["img_path"]) if it["type"] == "image" else it["text"] for it in res.content_list)
+    res.content_list, res.discarded = drop_running_lines(build_content_list(res.pages), len(res.pages))
+    res.markdown = content_markdown(res.content_list)
     res.text = combine_text(res.content_list, res.markdown)
     from ..utils.langid import detect
 
@@ -247,8 +355,9 @@ def assemble_packed(document_id: str, mode: str, shards: Sequence, extra: Dict[i
         slots.append((sh, k, None))
         content += sh.items(k, i, paths)
     res.pages = LazyPages(slots, document_id)
+    content, res.discarded = drop_running_lines(content, len(slots))
     res.content_list = content
-    res.markdown = "\n\n".join(("![](%s)" % it["img_path"]) if it["type"] == "image" else it["text"] for it in content)
+    res.markdown = content_markdown(content)
     res.text = combine_text(content, res.markdown)
     from ..utils.langid import detect
 

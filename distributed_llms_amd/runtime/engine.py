@@ -37,6 +37,7 @@ from ..ops import dbpost
 from ..ops import jpeg as jpeg_ops
 from ..ops import lstm as lstm_ops
 from ..ops import resample as rs
+from ..utils.scripts import resolve_scripts
 from . import layout
 
 
@@ -79,7 +80,8 @@ class TextLine:
     confidence: float
     block: int = 0               # text block (leaf region of the layout analysis); paragraphs never span blocks
     angle: float = 0.0           # radians the line is turned about the centre of ``box`` (skewed scans), 0 = upright
-    kind: str = "text"           # "equation": a display formula, ``text`` is its LaTeX source
+    kind: str = "text"           # "equation": a display formula, ``text`` is its LaTeX source; "cell": a cell of a
+                                 # table (the cells of one table share ``block`` and come row by row)
 
 
 @dataclass
@@ -377,7 +379,7 @@ class OcrEngine:
 
     def _det_boxes(self, db: _DetBatch) -> List[Tuple[np.ndarray, np.ndarray]]:
         """Wait for the detector of this batch.  Per page: (lines [n, 8] = x0, y0, x1, y1, score, block, angle, kind
-        (0 text line, 1 display formula) in reading order, figures [m, 5] = x0, y0, x1, y1, position in the reading
+        (0 text line, 1 display formula, 2 table cell) in reading order, figures [m, 5] = x0, y0, x1, y1, position in the reading
         sequence)."""
         cfg = self.cfg
         nfig = None
@@ -475,8 +477,10 @@ class OcrEngine:
             is_line = order < n
             lo = order[is_line]
             score = r[lo, 4:5] if r.shape[1] > 4 else np.ones((lo.size, 1), np.float32)
+            # kind: the detector's display-formula flag, else 2 for a cell of a table the layout analysis found
+            knd = np.where((kind[is_line] == 2) & (r[lo, 7] == 0), 2.0, r[lo, 7]).astype(np.float32)
             lines = np.concatenate([r[lo, :4], score, block[is_line][:, None].astype(np.float32), ang[lo][:, None],
-                                    r[lo, 7:8]], 1)
+                                    knd[:, None]], 1)
             pos = np.nonzero(~is_line)[0]
             fo = np.concatenate([fg[order[pos] - n], pos[:, None].astype(np.float32)], 1) if pos.size else np.zeros((0, 5), np.float32)
             out.append((lines.astype(np.float32), fo.astype(np.float32)))
@@ -497,9 +501,9 @@ class OcrEngine:
             knd = bx[:, 7].astype(np.int32) if n_det and bx.shape[1] > 7 else np.zeros((b5.shape[0],), np.int32)
             if p.layout_prior is not None and pi not in db.page_errors and not self._detections_usable(bx, p):
                 b4 = np.asarray(p.layout_prior, dtype=np.float32).reshape(-1, 4)
-                order, blk, _ = layout.order_page_native(b4, float(p.hw[0]))
+                order, blk, lk = layout.order_page_native(b4, float(p.hw[0]))
                 b5 = np.concatenate([b4[order], np.zeros((b4.shape[0], 1), np.float32)], 1)
-                knd = np.zeros((b5.shape[0],), np.int32)
+                knd = np.where(lk == 2, 2, 0).astype(np.int32)
                 used_prior = True
                 fg = fg[:0]
             b5 = b5[: cfg.max_lines_per_page]
@@ -513,7 +517,7 @@ class OcrEngine:
         kind = np.concatenate([pp[5] for pp in per_page], 0) if per_page else np.zeros((0,), np.int32)
         w = boxes[:, 2] - boxes[:, 0]
         h = boxes[:, 3] - boxes[:, 1]
-        ok = (w >= cfg.min_line_px) & (h >= cfg.min_line_px) & (kind == 0)
+        ok = (w >= cfg.min_line_px) & (h >= cfg.min_line_px) & (kind != 1)
         rot = (h > cfg.vertical_ratio * w).astype(np.int32)
         long_side = np.where(rot == 1, h, w)
         short_side = np.maximum(np.where(rot == 1, w, h), 1.0)
@@ -824,7 +828,7 @@ class OcrEngine:
                                             0.0, "equation"))
                 elif ok[gi]:
                     r.lines.append(TextLine(tuple(float(v) for v in b4[k, :4]), texts[gi], float(confs[gi]), int(blk[k]),
-                                            float(b4[k, 4])))
+                                            float(b4[k, 4]), "cell" if knd[k] == 2 else "text"))
             for k in range(fg.shape[0]):
                 crop = rb.fig_crops.get((pi, k))
                 if crop is not None:
@@ -841,7 +845,11 @@ class OcrEngine:
         a = ids.numpy()
         L = lens.numpy()
         ch = self._lut[np.clip(a, 0, len(self._lut) - 1)]
-        return [ch[i, : L[i]].tobytes().decode("utf-32-le") for i in range(a.shape[0])]
+        out = [ch[i, : L[i]].tobytes().decode("utf-32-le") for i in range(a.shape[0])]
+        if getattr(self.rec, "multi_script", False):
+            # shape classes -> code points (utils/scripts.py); ASCII lines are returned as they are
+            out = [t if t.isascii() else resolve_scripts(t) for t in out]
+        return out
 
     # ------------------------------------------------------------------ public API
     def process_batches(self, batches: Iterable[Sequence[PageImage]]) -> Iterator[List[PageResult]]:

@@ -68,13 +68,62 @@ class _Cutter:
         self.text_aspect = text_aspect
         self.order: List[int] = []
         self.block_of = np.zeros(boxes.shape[0], dtype=np.int32)
+        self.table_block: List[bool] = []       # per leaf: its boxes are the cells of a table, row by row
         self.n_blocks = 0
 
-    def leaf(self, idx: np.ndarray) -> None:
+    def leaf(self, idx: np.ndarray, table: bool = False) -> None:
+        self.table_block.append(table)
         for i in _rows_then_x(idx, self.b, self.h_med):
             self.order.append(i)
             self.block_of[i] = self.n_blocks
         self.n_blocks += 1
+
+    def rows_of(self, idx: np.ndarray) -> List[np.ndarray]:
+        """Rows of a region: boxes whose vertical centres lie within half a line height of the row's first box, each
+        row left to right (the order ``leaf`` emits)."""
+        b = self.b
+        cy = 0.5 * (b[idx, 1] + b[idx, 3])
+        o = idx[np.argsort(cy, kind="stable")]
+        cy = np.sort(cy, kind="stable")
+        rows, start = [], 0
+        for i in range(1, o.size + 1):
+            if i == o.size or cy[i] - cy[start] > 0.5 * self.h_med:
+                row = o[start:i]
+                rows.append(row[np.argsort(b[row, 0], kind="stable")])
+                start = i
+        return rows
+
+    def is_table(self, idx: np.ndarray, min_rows: int) -> bool:
+        """A region is a table when its boxes form a grid: at least ``min_rows`` rows of two or more cells each, the
+        cells of all rows falling into common columns (the whitespace between the columns runs through every row, at
+        least a line height wide), no row with two cells in one column, every column filled in at least half of the
+        rows, and at most one column of long text (two columns of running text whose lines happen to share baselines
+        are not a table).  Cells that wrap onto a second line are not handled: such a region stays ordinary text."""
+        b = self.b
+        if idx.size < 2 * min_rows:
+            return False
+        if np.any(b[idx, 3] - b[idx, 1] > 3.0 * self.h_med):      # a figure or a rotated line: no cell
+            return False
+        rows = self.rows_of(idx)
+        if len(rows) < min_rows or any(r.size < 2 for r in rows):
+            return False
+        cuts = sorted(0.5 * (s + e) for w, s, e in _gaps(b[idx, 0], b[idx, 2]) if w >= self.h_med)
+        if not cuts:
+            return False
+        C = len(cuts) + 1
+        filled = [0] * C
+        aspect: List[List[float]] = [[] for _ in range(C)]
+        ca = np.asarray(cuts)
+        for r in rows:
+            col = np.searchsorted(ca, b[r, 0] + 1e-6)
+            if np.unique(col).size != col.size:
+                return False
+            for i, c in zip(r, col):
+                filled[c] += 1
+                aspect[c].append(float((b[i, 2] - b[i, 0]) / max(b[i, 3] - b[i, 1], 1.0)))
+        if any(2 * f < len(rows) for f in filled):
+            return False
+        return sum(1 for a in aspect if float(np.median(a)) >= 10.0) <= 1
 
     def _is_text_column(self, idx: np.ndarray) -> bool:
         """A side of a vertical cut counts as a column of running text when it holds several lines that are much
@@ -102,6 +151,10 @@ class _Cutter:
             self.leaf(idx)
             return
         b = self.b
+        # 0. a grid of cells is read row by row, whatever its columns look like
+        if self.is_table(idx, 3):
+            self.leaf(idx, True)
+            return
         # 1. columns first: a gutter that runs through the whole region means the columns are read one after another
         cuts = self.column_cuts(idx)
         if cuts:
@@ -117,6 +170,14 @@ class _Cutter:
                 # on one baseline with the same gap below them, and cutting there would read the headings across.
                 i = 0
                 while i < len(parts):
+                    # the rows of a table whose row spacing is as large as a block gap belong together
+                    j = i
+                    while j + 1 < len(parts) and self.is_table(np.concatenate(parts[i : j + 2]), 2):
+                        j += 1
+                    if j > i and self.is_table(np.concatenate(parts[i : j + 1]), 3):
+                        self.leaf(np.concatenate(parts[i : j + 1]), True)
+                        i = j + 1
+                        continue
                     j = i
                     while j + 1 < len(parts) and self.column_cuts(np.concatenate(parts[i : j + 2])):
                         j += 1
@@ -141,15 +202,19 @@ class _Cutter:
 
 
 def reading_order(boxes: np.ndarray, col_gap: float = 1.2, block_gap: float = 0.9, min_col_lines: int = 3,
-                  text_aspect: float = 4.0) -> Tuple[np.ndarray, np.ndarray]:
+                  text_aspect: float = 4.0, with_tables: bool = False):
     """Recursive XY-cut.  ``col_gap`` / ``block_gap`` are the minimum whitespace for a vertical / horizontal cut in
-    units of the median box height.  Returns (order, block id per box)."""
+    units of the median box height.  Returns (order, block id per box) and, ``with_tables``, a bool per box: it is a
+    cell of a table (the cells of one table share a block and come row by row)."""
     boxes = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)
     n = boxes.shape[0]
     if n == 0:
-        return np.zeros((0,), np.int64), np.zeros((0,), np.int32)
+        e = (np.zeros((0,), np.int64), np.zeros((0,), np.int32))
+        return e + (np.zeros((0,), bool),) if with_tables else e
     c = _Cutter(boxes, col_gap, block_gap, min_col_lines, text_aspect)
     c.cut(np.arange(n))
+    if with_tables:
+        return np.asarray(c.order, dtype=np.int64), c.block_of, np.asarray(c.table_block, bool)[c.block_of]
     return np.asarray(c.order, dtype=np.int64), c.block_of
 
 
@@ -207,13 +272,13 @@ def order_page(boxes: np.ndarray, page_h: float, figures: Optional[np.ndarray] =
     keep their place in the sequence), footer lines.
 
     Returns (order, block id, kind) where ``order`` indexes the concatenation [boxes ; figures] and ``kind`` is 0 for
-    a text line and 1 for a figure, aligned with ``order``."""
+    a text line, 1 for a figure and 2 for a cell of a table, aligned with ``order``."""
     boxes = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)
     figs = np.zeros((0, 4)) if figures is None else np.asarray(figures, dtype=np.float64).reshape(-1, 4)
     nb = boxes.shape[0]
     head, body, foot = split_margins(boxes, page_h)
     allb = np.concatenate([boxes[body], figs], axis=0)
-    order_b, block_b = reading_order(allb)
+    order_b, block_b, cell_b = reading_order(allb, with_tables=True)
     order: List[int] = []
     block: List[int] = []
     nblk = 0
@@ -232,4 +297,8 @@ def order_page(boxes: np.ndarray, page_h: float, figures: Optional[np.ndarray] =
     block += [nblk] * len(o)
     order_a = np.asarray(order, dtype=np.int64)
     kind = (order_a >= nb).astype(np.int32)
+    n_head = len(head)
+    for k, i in enumerate(order_b):
+        if cell_b[i] and i < body.size:
+            kind[n_head + k] = 2
     return order_a, np.asarray(block, dtype=np.int32), kind

@@ -24,8 +24,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 MAGIC = b"DLS1"
-ITEM_TEXT, ITEM_EQUATION, ITEM_IMAGE = 0, 1, 2
-_KINDS = ("text", "equation", "image")
+ITEM_TEXT, ITEM_EQUATION, ITEM_IMAGE, ITEM_TABLE, ITEM_MARGIN_TOP, ITEM_MARGIN_BOTTOM = 0, 1, 2, 3, 4, 5
+_LINE_KINDS = ("text", "equation", "cell")
 
 
 def _png(arr: np.ndarray) -> bytes:
@@ -71,7 +71,7 @@ def pack_shard(pages: Sequence[Tuple[int, Optional[object]]], items_of=None) -> 
                 conf.append(ln.confidence)
                 block.append(ln.block)
                 angle.append(ln.angle)
-                kind.append(1 if ln.kind == "equation" else 0)
+                kind.append(_LINE_KINDS.index(ln.kind) if ln.kind in _LINE_KINDS else 0)
                 texts.append(ln.text)
             base = len(f_png)
             for fg in pr.figures:
@@ -80,10 +80,19 @@ def pack_shard(pages: Sequence[Tuple[int, Optional[object]]], items_of=None) -> 
                 f_png.append(_png(fg.image) if fg.image is not None else b"")
             for it in items_of(pr):
                 t = it["type"]
-                i_kind.append(ITEM_IMAGE if t == "image" else (ITEM_EQUATION if t == "equation" else ITEM_TEXT))
+                if t == "table":
+                    # cells never hold a tab or a line break: rows on lines, cells between tabs
+                    i_kind.append(ITEM_TABLE)
+                    i_texts.append("\n".join("\t".join(c.replace("\t", " ").replace("\n", " ") for c in row)
+                                             for row in it["cells"]))
+                elif t == "text" and it.get("margin"):
+                    i_kind.append(ITEM_MARGIN_TOP if it["margin"] == "top" else ITEM_MARGIN_BOTTOM)
+                    i_texts.append(it["text"])
+                else:
+                    i_kind.append(ITEM_IMAGE if t == "image" else (ITEM_EQUATION if t == "equation" else ITEM_TEXT))
+                    i_texts.append(it.get("text", ""))
                 i_box.append(tuple(it.get("bbox") or (0.0, 0.0, 0.0, 0.0)))
                 i_fig.append(base + int(it.get("figure", 0)) if t == "image" else -1)
-                i_texts.append(it.get("text", ""))
         line_off[k + 1] = len(texts)
         item_off[k + 1] = len(i_kind)
         fig_off[k + 1] = len(f_png)
@@ -207,6 +216,13 @@ class PackedShard:
             elif kd == ITEM_EQUATION:
                 out.append({"type": "equation", "text": t[off[j] : off[j + 1]], "text_format": "latex", "page_idx": pi,
                             "bbox": [round(float(v), 1) for v in self.i_box[j]]})
+            elif kd == ITEM_TABLE:
+                from .document import table_item
+
+                out.append(table_item([r.split("\t") for r in t[off[j] : off[j + 1]].split("\n")], pi, self.i_box[j]))
+            elif kd in (ITEM_MARGIN_TOP, ITEM_MARGIN_BOTTOM):
+                out.append({"type": "text", "text": t[off[j] : off[j + 1]], "page_idx": pi,
+                            "margin": "top" if kd == ITEM_MARGIN_TOP else "bottom"})
             else:
                 out.append({"type": "text", "text": t[off[j] : off[j + 1]], "page_idx": pi})
         return out
@@ -223,7 +239,7 @@ class PackedShard:
         bx, cf, bl, an, kd = self.boxes, self.conf, self.block, self.angle, self.kind
         for j in range(int(self.line_off[k]), int(self.line_off[k + 1])):
             pr.lines.append(TextLine(tuple(float(v) for v in bx[j]), t[off[j] : off[j + 1]], float(cf[j]), int(bl[j]),
-                                     float(an[j]), "equation" if kd[j] else "text"))
+                                     float(an[j]), _LINE_KINDS[int(kd[j])] if int(kd[j]) < len(_LINE_KINDS) else "text"))
         for f in range(int(self.fig_off[k]), int(self.fig_off[k + 1])):
             pr.figures.append(Figure(tuple(float(v) for v in self.f_box[f]), int(self.f_order[f]), None, ""))
         return pr

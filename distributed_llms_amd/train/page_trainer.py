@@ -33,7 +33,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from ..models.crnn import CRNN, DEFAULT_CHARSET
+from ..models.crnn import CRNN, DEFAULT_CHARSET, MULTI_CHARSET
 from ..models.dbnet import DBNet
 from ..ops import ctc_loss as ctc_ops
 from ..ops import resample as rs
@@ -59,15 +59,20 @@ def augment_scan(pg: np.ndarray, rng: np.random.Generator) -> np.ndarray:
 
 
 def render_training_page(seed: int, fonts=None, plain_share: float = 0.2, max_skew: float = 5.0, formula_share: float = 0.4,
-                         i18n_share: float = 0.35):
+                         i18n_share: float = 0.35, script_share: float = 0.0):
     """One page of the training distribution (see the module docstring) and its truth.  ``i18n_share`` of the layout
-    pages are written in the Western European vocabulary (accented letters, sharp s, ligatures, currency signs)."""
+    pages are written in the Western European vocabulary (accented letters, sharp s, ligatures, currency signs);
+    ``script_share`` of them in Russian or Greek (half each, ``utils.scripts``)."""
     rng = np.random.default_rng(seed)
     if rng.random() < plain_share:
         pg, truth = synth.render_page(seed, font_px=int(rng.integers(34, 50)), noise=float(rng.uniform(0.5, 4.0)))
         return pg, truth
     skew = float(rng.uniform(-max_skew, max_skew)) if rng.random() < 0.7 else 0.0
     blur = float(rng.uniform(0.3, 1.1)) if rng.random() < 0.4 else 0.0
+    if script_share > 0 and np.random.default_rng(seed ^ 0x5C21).random() < script_share:
+        pg, truth = synth.render_layout_page(seed, fonts=fonts or synth.TRAIN_FONTS, skew=skew, blur=blur,
+                                             noise=float(rng.uniform(0.5, 5.0)), script="cyrillic" if seed % 2 else "greek")
+        return augment_scan(pg, rng), truth
     pg, truth = synth.render_layout_page(seed, fonts=fonts or synth.TRAIN_FONTS, skew=skew, blur=blur,
                                          noise=float(rng.uniform(0.5, 5.0)),
                                          formulas=float(rng.uniform(0.3, 0.9)) if rng.random() < formula_share else 0.0,
@@ -78,9 +83,11 @@ def render_training_page(seed: int, fonts=None, plain_share: float = 0.2, max_sk
 class PageProducer:
     """Renders pages on host threads and keeps a bounded queue of (uint8 page tensor on device, truth)."""
 
-    def __init__(self, device, threads: int = 6, depth: int = 24, seed0: int = 100_000, fonts=None):
+    def __init__(self, device, threads: int = 6, depth: int = 24, seed0: int = 100_000, fonts=None,
+                 script_share: float = 0.0):
         self.device = device
         self.fonts = fonts
+        self.script_share = script_share
         self.q: "queue.Queue" = queue.Queue(maxsize=depth)
         self._seed = seed0
         self._lock = threading.Lock()
@@ -94,7 +101,7 @@ class PageProducer:
             with self._lock:
                 self._seed += 1
                 seed = self._seed
-            pg, truth = render_training_page(seed, self.fonts)
+            pg, truth = render_training_page(seed, self.fonts, script_share=self.script_share)
             while not self._stop.is_set():
                 try:
                     self.q.put((torch.from_numpy(pg), truth), timeout=1.0)
@@ -393,6 +400,11 @@ def evaluate(det, rec, device, seeds, verbose=False, formula_weights=None):
     out["western_european_held_out_fonts"] = evaluate_pages(
         eng, [synth.render_layout_page(sd, fonts=lato, i18n=1.0, layout=synth.LAYOUTS[k % len(synth.LAYOUTS)],
                                        skew=2.0 * (1 if k % 2 == 0 else -1)) for k, sd in enumerate(seeds[:6])], verbose)
+    if rec.multi_script:
+        for name, sc in (("russian_held_out_fonts", "cyrillic"), ("greek_held_out_fonts", "greek")):
+            out[name] = evaluate_pages(
+                eng, [synth.render_layout_page(sd, fonts=lato, script=sc, layout=synth.LAYOUTS[k % len(synth.LAYOUTS)],
+                                               skew=2.0 * (1 if k % 2 == 0 else -1)) for k, sd in enumerate(seeds[:6])], verbose)
     out["formula_pages"] = evaluate_pages(eng, [synth.render_layout_page(sd, fonts=synth.TRAIN_FONTS, formulas=0.8,
                                                                          layout=synth.LAYOUTS[k % 3])
                                                 for k, sd in enumerate(seeds[:4])], verbose)
@@ -401,9 +413,9 @@ def evaluate(det, rec, device, seeds, verbose=False, formula_weights=None):
     return out
 
 
-def write_meta(out_dir: str, steps: int, ev, log, charset: str = "") -> None:
+def write_meta(out_dir: str, steps: int, ev, log, charset: str = "", history: str = "") -> None:
     """``train_meta.json``: what the weights were trained on (fonts drawn, fonts never drawn) and how they score."""
-    json.dump({"steps": steps, "eval": ev, "log": log[-20:], "charset": charset,
+    json.dump({"steps": steps, "eval": ev, "log": log[-20:], "charset": charset, "history": history,
                "train_fonts": synth.available_fonts(synth.TRAIN_FONTS),
                "held_out_fonts": synth.available_fonts(synth.HELD_OUT_FONTS),
                "augmentation": {"skew_deg": 5.0, "blur_sigma": [0.3, 1.1], "noise_sigma": [0.5, 5.0],
@@ -425,6 +437,12 @@ def main(argv=None) -> int:
     ap.add_argument("--time-limit", type=float, default=900.0, help="stop cleanly (and save) after this many seconds")
     ap.add_argument("--threads", type=int, default=12)
     ap.add_argument("--init", default="", help="directory with weights to start from (step count restarts at 0)")
+    ap.add_argument("--charset", choices=("latin", "multi"), default="latin",
+                    help="multi: Latin + Cyrillic + Greek shape classes (utils/scripts.py)")
+    ap.add_argument("--script-share", type=float, default=0.0, help="share of the layout pages written in Russian / Greek")
+    ap.add_argument("--rec-only", action="store_true", help="leave the detector as it is: recogniser steps only")
+    ap.add_argument("--lines", type=int, default=64, help="line crops per recogniser step")
+    ap.add_argument("--history", default="", help="free text recorded in train_meta.json")
     ap.add_argument("--library-convs", action="store_true",
                     help="recogniser convolutions through the library instead of the in-repo training kernels (ops/conv_train.py)")
     args = ap.parse_args(argv)
@@ -451,10 +469,11 @@ def main(argv=None) -> int:
         if os.path.exists(meta):
             start = int(json.load(open(meta)).get("steps", 0))
         print(f"resumed weights from {args.out} (step {start})", flush=True)
-    if rec.charset != DEFAULT_CHARSET:
+    want = MULTI_CHARSET if args.charset == "multi" else DEFAULT_CHARSET
+    if rec.charset != want and len(rec.charset) < len(want):
         # weights trained on fewer characters: grow the classifier, old classes keep their rows
         n_old = len(rec.charset)
-        rec.set_charset(DEFAULT_CHARSET)
+        rec.set_charset(want)
         rec.to(device)
         print(f"character set grown from {n_old} to {len(rec.charset)} characters", flush=True)
     det.train()
@@ -462,7 +481,7 @@ def main(argv=None) -> int:
     rec.own_conv_train = device.type == "cuda" and not args.library_convs
     dopt, ropt = _Opt(det, args.det_lr), _Opt(rec, args.rec_lr)
     it = start
-    prod = PageProducer(device, threads=args.threads)
+    prod = PageProducer(device, threads=args.threads, script_share=args.script_share)
     t0 = time.perf_counter()
     alive = threading.Event()
 
@@ -477,16 +496,18 @@ def main(argv=None) -> int:
         while it < args.steps and time.perf_counter() - t0 < args.time_limit:
             pages = [prod.get() for _ in range(3)]
             # ---- detector step
-            x, tgt, ftgt = det_batch(pages, device)
-            dopt.zero()
-            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-                prob, flogit = det.forward_all(x)
-            ld = det_loss(prob, tgt)
-            lf = fig_loss(flogit, ftgt)
-            (ld + 0.5 * lf).backward()
-            dopt.step(it, args.steps)
+            ld = lf = 0.0
+            if not args.rec_only:
+                x, tgt, ftgt = det_batch(pages, device)
+                dopt.zero()
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                    prob, flogit = det.forward_all(x)
+                ld = det_loss(prob, tgt)
+                lf = fig_loss(flogit, ftgt)
+                (ld + 0.5 * lf).backward()
+                dopt.step(it, args.steps)
             # ---- recognizer step
-            xr, il, tg, tl, _ = rec_batch(pages, rec, device)
+            xr, il, tg, tl, _ = rec_batch(pages, rec, device, max_lines=args.lines)
             ropt.zero()
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
                 logits = rec(xr, il)
@@ -506,7 +527,7 @@ def main(argv=None) -> int:
                 print(json.dumps({"step": it, "eval": ev}), flush=True)
                 save_bf16(det, dp)
                 save_bf16(rec, rp)
-                write_meta(args.out, it, ev, log, rec.charset)
+                write_meta(args.out, it, ev, log, rec.charset, args.history)
     finally:
         prod.stop()
         alive.set()
@@ -514,7 +535,7 @@ def main(argv=None) -> int:
                   formula_weights=fw)
     save_bf16(det, dp)
     save_bf16(rec, rp)
-    write_meta(args.out, it, ev, log, rec.charset)
+    write_meta(args.out, it, ev, log, rec.charset, args.history)
     print(json.dumps({"final_step": it, "eval": ev, "weights": args.out}), flush=True)
     return 0
 

@@ -1,0 +1,126 @@
+"""Cyrillic and Greek next to Latin in ONE recogniser: visual classes and script resolution.
+
+The reference downloads one multilingual recogniser and lets its engine pick by document language
+(services/ocr_service/download_models_hf.py:41, services/ocr_service/ocr_service.py:215-220).  A printed Cyrillic
+``А`` or Greek ``Α`` is the same shape as a Latin ``A``: a classifier with a class per code point would have to guess
+between identical glyphs.  So the recogniser's classes are *shapes*:
+
+* letters of the three alphabets that share a shape share the Latin class (``HOMOGLYPHS``: 20 Cyrillic and 16 Greek
+  code points);
+* the letters only one alphabet has (``CYRILLIC_EXTRA``, ``GREEK_EXTRA``) are classes of their own, appended to the
+  Latin character set - a model grown from Latin weights keeps its class indices.
+
+``to_visual`` maps truth text to classes for training; ``resolve_scripts`` turns a decoded line back into code
+points: a word that holds a Cyrillic-only (Greek-only) letter is Cyrillic (Greek) and its shared shapes become that
+alphabet's letters; a word made of shared shapes only ("сорт" without the т, "о", "а") follows the majority of the
+line.  Lines without a non-Latin class take a fast path and come back unchanged.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+# letters that no Latin letter looks like, in alphabet order
+CYRILLIC_EXTRA = "БГДЖЗИЙЛПУФЦЧШЩЪЫЬЭЮЯ" "бвгджзийклмнптфцчшщъыьэюя" "№"
+GREEK_EXTRA = "ΓΔΘΛΞΠΣΦΨΩ" "αβγδεζηθικλμνξπρστυφχψως" "άέήίύώ" "ΆΈΉΊΌΎΏ"
+
+# code point -> the Latin character whose class it shares
+_CYR_TO_LATIN = dict(zip("АВЕКМНОРСТХаеорсухЁё", "ABEKMHOPCTXaeopcyxËë"))
+_GRK_TO_LATIN = dict(zip("ΑΒΕΖΗΙΚΜΝΟΡΤΥΧοό", "ABEZHIKMNOPTYXoó"))
+HOMOGLYPHS: Dict[str, str] = {**_CYR_TO_LATIN, **_GRK_TO_LATIN}
+_LATIN_TO_CYR = {v: k for k, v in _CYR_TO_LATIN.items()}
+_LATIN_TO_GRK = {v: k for k, v in _GRK_TO_LATIN.items()}
+# near-shapes the recogniser may pick inside a word of the other alphabet; applied only to words already known to be
+# Cyrillic / Greek from their unambiguous letters
+_LATIN_TO_CYR_SOFT = {**_LATIN_TO_CYR, "k": "к"}
+_LATIN_TO_GRK_SOFT = {**_LATIN_TO_GRK, "v": "ν", "u": "υ", "k": "κ", "i": "ι"}
+
+_CYR_ONLY = frozenset(CYRILLIC_EXTRA) - {"№"}
+_GRK_ONLY = frozenset(GREEK_EXTRA)
+_SHARED = frozenset(HOMOGLYPHS.values())
+_VISUAL = str.maketrans(HOMOGLYPHS)
+_TO_CYR = str.maketrans(_LATIN_TO_CYR_SOFT)
+_TO_GRK = str.maketrans(_LATIN_TO_GRK_SOFT)
+_TO_CYR_HARD = str.maketrans(_LATIN_TO_CYR)
+_TO_GRK_HARD = str.maketrans(_LATIN_TO_GRK)
+
+
+def to_visual(text: str) -> str:
+    """Truth text -> the recogniser's classes (shared shapes written as their Latin letter)."""
+    return text if text.isascii() else text.translate(_VISUAL)
+
+
+def _counts(word: str):
+    cyr = grk = lat = 0
+    for c in word:
+        if c in _CYR_ONLY:
+            cyr += 1
+        elif c in _GRK_ONLY:
+            grk += 1
+        elif c.isalpha() and c not in _SHARED:
+            lat += 1
+    return cyr, grk, lat
+
+
+def line_script(text: str) -> str:
+    """``latin``, ``cyrillic`` or ``greek``: the alphabet most of the unambiguous letters of a decoded line belong to."""
+    if text.isascii():
+        return "latin"
+    cyr, grk, lat = _counts(text)
+    if cyr > max(grk, lat):
+        return "cyrillic"
+    if grk > max(cyr, lat):
+        return "greek"
+    return "latin"
+
+
+def resolve_scripts(text: str, hint: Optional[str] = None) -> str:
+    """Decoded classes -> code points.  ``hint``: the script of the surrounding text (a page or document majority) for
+    lines that consist of shared shapes only."""
+    if text.isascii() and hint in (None, "latin"):
+        return text
+    dom = line_script(text)
+    if dom == "latin" and hint in ("cyrillic", "greek") and _counts(text)[2] == 0:
+        dom = hint
+    if dom == "latin" and not (_CYR_ONLY.intersection(text) or _GRK_ONLY.intersection(text)):
+        return text
+    out = []
+    for word in text.split(" "):
+        cyr, grk, lat = _counts(word)
+        if cyr and cyr >= max(grk, lat):
+            word = word.translate(_TO_CYR)
+        elif grk and grk >= max(cyr, lat):
+            word = word.translate(_TO_GRK)
+        elif lat == 0 and dom == "cyrillic":
+            word = word.translate(_TO_CYR_HARD)
+        elif lat == 0 and dom == "greek":
+            word = word.translate(_TO_GRK_HARD)
+        out.append(word)
+    return " ".join(out)
+
+
+# ------------------------------------------------------------------------------------------------ vocabularies
+# High-frequency and document words for synthetic pages; together they use every letter of the two alphabets.
+WORDS_RU = (
+    "и в не на я что он с как а то это по но все она так его же за от было бы у мы к вы из они для при ещё уже "
+    "или если только когда может быть есть нет да где кто чем этот который свой наш ваш один два три год время "
+    "дело жизнь день рука раз работа слово место вопрос сторона страна мир случай голова ребёнок сила конец вид "
+    "система часть город отношение женщина деньги земля машина вода отец проблема час право решение дверь образ "
+    "история власть закон война книга возможность результат область статья число компания народ группа развитие "
+    "процесс условие средство начало государство уровень форма связь минута качество действие правительство "
+    "документ страница таблица рисунок глава раздел приложение отчёт счёт сумма итого дата номер подпись договор "
+    "общество директор бухгалтер заявление справка адрес телефон объект эксперт юрист цель язык щит съезд подъезд "
+    "Москва Россия Петербург Фёдор Юрий Цветаева Чехов Шишкин Щедрин Эльбрус Яков Жуков Зоя Иван Йошкар Люба Пётр "
+    "Ульяна Фома Харьков Гоголь Дон Байкал Владимир Ярославль Эрмитаж Южный Центр Чайковский Шаляпин Ъ Ы Ь "
+    "№ 15 2024 г. 1 250,00 руб. 37% стр. 12 (а) [3] т. е. и т. д."
+).split()
+WORDS_EL = (
+    "και το να η ο του της με που τα για από δεν θα την στο είναι σε τον των μου ένα μια αλλά αυτό σου στην όπως τι "
+    "οι τους αν κι μας στη ή ότι πως είχε ήταν έχει πιο όλα μετά πολύ εκεί τώρα πριν όταν γιατί χρόνια ημέρα χρόνος "
+    "άνθρωπος ζωή κόσμος πόλη χώρα νερό δουλειά λόγος μέρος πράγμα παιδί γυναίκα άντρας σπίτι χέρι μάτι φορά ώρα "
+    "βιβλίο έγγραφο σελίδα πίνακας εικόνα κεφάλαιο ενότητα παράρτημα αναφορά σύνολο ποσό ημερομηνία αριθμός υπογραφή "
+    "σύμβαση εταιρεία διευθυντής αίτηση διεύθυνση τηλέφωνο αποτέλεσμα σύστημα ανάπτυξη κυβέρνηση νόμος ιστορία ψυχή "
+    "ξένος ζήτημα θέμα φως ψωμί ξύλο γλώσσα δρόμος ύψος ώμος ήλιος έργο ίδιος "
+    "Αθήνα Ελλάδα Θεσσαλονίκη Γιώργος Δημήτρης Ζωή Ηλίας Θεός Ιωάννης Κώστας Λάρισα Μαρία Νίκος Ξάνθη Ολυμπία "
+    "Πάτρα Ρόδος Σπάρτη Τρίκαλα Υπάτη Φώτης Χανιά Ψαρά Ωρωπός Βόλος Γ Δ Θ Λ Ξ Π Σ Φ Ψ Ω "
+    "15 2024 1.250,00 € 37% σελ. 12 (α) [3] κ.λπ. π.χ."
+).split()

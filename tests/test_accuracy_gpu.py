@@ -173,3 +173,68 @@ def test_western_european_text_in_held_out_fonts(pipe):
     lost = sum((Counter(want_acc) - Counter(got_acc)).values())
     assert lost <= 0.06 * len(want_acc), (lost, len(want_acc))
     assert doc.language != "en" and doc.language != "und", (doc.language, doc.language_confidence)
+
+
+def test_scanned_table_becomes_a_table_item_with_its_cells(pipe):
+    """A ruled 5 x 3 table between two paragraphs of a scan: one 'table' item whose cells are the printed ones, row by
+    row; the paragraphs around it stay text."""
+    pg, tr, grid = synth.render_table_page(31_337, rows=5, cols=3, ruled=True)
+    doc = pipe.process_pdf(synth.make_scanned_pdf([pg], codec="jpeg"), "table")
+    tabs = [it for it in doc.content_list if it["type"] == "table"]
+    assert len(tabs) == 1, [it["type"] for it in doc.content_list]
+    cells = tabs[0]["cells"]
+    assert len(cells) == 5 and all(len(r) == 3 for r in cells), cells
+    flat_got, flat_want = " ".join(c for r in cells for c in r), " ".join(c for r in grid for c in r)
+    assert _cer(flat_got, flat_want) < 0.03, (flat_got, flat_want)
+    assert tabs[0]["table_body"].count("<td>") == 15 and tabs[0]["text"] in doc.text
+    k = doc.content_list.index(tabs[0])
+    assert 0 < k < len(doc.content_list) - 1
+    # a table inside one column of a two-column page
+    pg2, _, grid2 = synth.render_table_page(31_338, rows=4, cols=3, ruled=False, column=True)
+    doc2 = pipe.process_pdf(synth.make_scanned_pdf([pg2], codec="jpeg"), "table2")
+    tabs2 = [it for it in doc2.content_list if it["type"] == "table"]
+    assert len(tabs2) == 1 and len(tabs2[0]["cells"]) == 4
+    assert _cer(" ".join(c for r in tabs2[0]["cells"] for c in r), " ".join(c for r in grid2 for c in r)) < 0.03
+
+
+def test_running_header_and_page_numbers_are_left_out_of_a_scanned_document(pipe):
+    """Four scanned pages that all carry the same running header and a page number: neither reaches the combined
+    text; the body does."""
+    from PIL import Image, ImageDraw
+
+    pages, bodies = [], []
+    for k in range(4):
+        pg, tr = synth.render_layout_page(88_000 + k, layout="single", fonts=["DejaVuSerif.ttf"], header_footer=False)
+        im = Image.fromarray(pg)
+        d = ImageDraw.Draw(im)
+        f = synth.named_font("DejaVuSerif.ttf", 34)
+        d.text((200, 90), "Quarterly Shard Report", fill=30, font=f)
+        d.text((1180, 3330), "- %d -" % (k + 11), fill=30, font=f)
+        pages.append(np.asarray(im))
+        bodies.append(tr.texts)
+    doc = pipe.process_pdf(synth.make_scanned_pdf(pages, codec="jpeg"), "running")
+    assert "Quarterly Shard Report" not in doc.text and "- 12 -" not in doc.text
+    kinds = sorted(d["type"] for d in doc.discarded)
+    assert kinds.count("header") == 4 and kinds.count("footer") == 4, doc.discarded
+    flat = " ".join(doc.text.split())
+    assert _cer(flat, " ".join(" ".join(" ".join(b) for b in bodies).split())) < 0.02
+
+
+@pytest.mark.parametrize("script,probe", [("cyrillic", "жщыюя"), ("greek", "λπσωθ")])
+def test_russian_and_greek_pages_in_held_out_fonts(pipe, script, probe):
+    """Pages written in Russian / Greek (one word in ten English) in fonts the training never drew, turned by +-2
+    degrees, through detector boxes: the shape classes come back as the alphabet's own code points."""
+    from distributed_llms_amd.train.page_trainer import evaluate_pages
+
+    if not getattr(pipe.engine.rec, "multi_script", False):
+        pytest.skip("the shipped recogniser has no Cyrillic / Greek classes")
+    lato = [f for f in synth.HELD_OUT_FONTS if f.startswith("Lato")]
+    pages = [synth.render_layout_page(654_000 + k, fonts=lato, script=script, layout=synth.LAYOUTS[k % len(synth.LAYOUTS)],
+                                      skew=2.0 * (1 if k % 2 == 0 else -1)) for k in range(4)]
+    assert sum(c in probe for _, tr in pages for t in tr.texts for c in t) > 50
+    ev = evaluate_pages(pipe.engine, pages)
+    print(script, "held-out fonts:", ev)
+    assert ev["det_recall"] > 0.97, ev
+    assert ev["cer"] < 0.04, ev
+    doc = pipe.process_pdf(synth.make_scanned_pdf([pages[0][0]], codec="jpeg"), script)
+    assert doc.language == script, (doc.language, doc.language_confidence)

@@ -546,7 +546,7 @@ def test_bn_relu_training_kernels_match_pytorch(shape, act):
     assert int(bn.num_batches_tracked) == 1
 
 
-@pytest.mark.parametrize("M,K,N", [(4096, 512, 2048), (1000, 512, 164), (256, 64, 192), (777, 128, 72)])
+@pytest.mark.parametrize("M,K,N", [(4096, 512, 2048), (1000, 512, 164), (256, 64, 192), (777, 128, 72), (900, 512, 258)])
 def test_linear_train_function_matches_autograd(M, K, N):
     """ops/linear_train.py (forward and data gradient on the GEMM kernels, weight gradient on the split-K kernel as a
     1 x 1 convolution) against PyTorch autograd in fp32 on the same bf16-rounded operands."""

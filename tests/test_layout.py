@@ -162,3 +162,84 @@ def test_formulas_become_equation_items_in_reading_order():
     # equations split the text flow: no paragraph spans a formula
     order = [it["type"] for it in items]
     assert order[0] == "text" and "equation" in order[1:-1]
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(rows=4, cols=2), dict(row_pitch=2.6), dict(column=True, cols=3),
+                                dict(rows=8, cols=5, ruled=False)])
+def test_tables_are_found_and_read_row_by_row(kw):
+    """A grid of cells is one block of kind 2 in row-major order - with tight rows, with rows a block gap apart, and
+    inside one column of a two-column page - in the native implementation and in the Python oracle alike."""
+    for seed in range(4):
+        arr, tr, grid = synth.render_table_page(40 + seed, size=(1240, 1754), **kw)
+        a = layout.order_page(tr.boxes, arr.shape[0])
+        b = layout.order_page_native(tr.boxes, float(arr.shape[0]))
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+        order, block, kind = b
+        assert order.tolist() == list(range(len(tr.texts)))
+        cells = [tr.texts[i] for i, k in zip(order, kind) if k == 2]
+        assert cells == [c for row in grid for c in row]
+        assert len({int(bk) for bk, k in zip(block, kind) if k == 2}) == 1
+
+
+def test_table_becomes_one_content_item_and_survives_the_wire():
+    from distributed_llms_amd.runtime.document import page_content_items
+    from distributed_llms_amd.runtime.engine import PageResult, TextLine
+    from distributed_llms_amd.runtime.wire import PackedShard, pack_shard
+
+    arr, tr, grid = synth.render_table_page(7, size=(1240, 1754), rows=4, cols=3)
+    grid[2][1] = "a | b <c>"                       # separators and markup inside a cell must not break anything
+    flat = [c for row in grid for c in row]
+    order, block, kind = layout.order_page_native(tr.boxes, float(arr.shape[0]))
+    pr = PageResult("d", 0, arr.shape[1], arr.shape[0])
+    n_before = tr.texts.index(grid[0][0])
+    texts = tr.texts[:n_before] + flat + tr.texts[n_before + len(flat):]
+    for k, i in enumerate(order):
+        pr.lines.append(TextLine(tuple(float(v) for v in tr.boxes[i]), texts[i], 0.9, int(block[k]), 0.0,
+                                 "cell" if kind[k] == 2 else "text"))
+    items = page_content_items(pr)
+    tabs = [it for it in items if it["type"] == "table"]
+    assert len(tabs) == 1 and tabs[0]["cells"] == grid
+    assert tabs[0]["table_body"].count("<tr>") == 4 and tabs[0]["table_body"].count("<td>") == 12
+    assert "a | b &lt;c&gt;" in tabs[0]["table_body"]
+    assert tabs[0]["text"].split("\n")[0] == " | ".join(grid[0])
+    kinds = [it["type"] for it in items]
+    k = kinds.index("table")
+    assert 0 < k < len(kinds) - 1 and set(kinds[:k]) == {"text"} and set(kinds[k + 1:]) == {"text"}
+    sh = PackedShard(pack_shard([(0, pr)]))
+    back = sh.items(0)
+    assert [it["type"] for it in back] == kinds
+    assert back[k]["cells"] == grid and back[k]["table_body"] == tabs[0]["table_body"] and back[k]["text"] == tabs[0]["text"]
+    assert [l.kind for l in sh.page_result(0).lines] == [l.kind for l in pr.lines]
+
+
+def test_running_headers_and_footers_leave_the_content_list():
+    """Lines in the margin bands that repeat across pages (digits aside) are dropped from the content list and kept
+    in ``discarded``; a margin line that does not repeat stays, and a one-page document keeps everything."""
+    from distributed_llms_amd.runtime.document import assemble_document, assemble_packed
+    from distributed_llms_amd.runtime.engine import PageResult, TextLine
+    from distributed_llms_amd.runtime.wire import PackedShard, pack_shard
+
+    def page(i, header, footer):
+        pr = PageResult("doc", i, 1000, 1400)
+        pr.lines.append(TextLine((100, 40, 600, 70), header, 0.9, 0))
+        pr.lines.append(TextLine((100, 200, 900, 240), f"body line one of page {i}", 0.9, 1))
+        pr.lines.append(TextLine((100, 245, 900, 285), "and its second line", 0.9, 1))
+        pr.lines.append(TextLine((450, 1330, 550, 1360), footer, 0.9, 2))
+        return pr
+
+    pages = [page(i, "Annual Report 2024" if i != 2 else "Chapter Three Begins", f"Page {i + 1} of 5") for i in range(5)]
+    res = assemble_document("doc", "ocr", pages)
+    texts = [it["text"] for it in res.content_list]
+    assert not any("Annual Report" in t or t.startswith("Page ") for t in texts)
+    assert "Chapter Three Begins" in texts                               # a margin line that does not repeat is content
+    assert sum(1 for t in texts if t.startswith("body line one")) == 5
+    assert sorted(d["type"] for d in res.discarded) == ["footer"] * 5 + ["header"] * 4
+    assert all("margin" not in it for it in res.content_list)
+    assert "Annual Report" not in res.text and "Chapter Three Begins" in res.text
+    # the packed path (GPU workers -> front end) decides over the whole document too, not per shard
+    shards = [PackedShard(pack_shard([(i, pages[i]) for i in idx])) for idx in ((0, 1), (2, 3, 4))]
+    res2 = assemble_packed("doc", "ocr", shards, {}, 5)
+    assert [it["text"] for it in res2.content_list] == texts and res2.discarded == res.discarded
+    one = assemble_document("doc", "ocr", pages[:1])
+    assert any("Annual Report" in it["text"] for it in one.content_list) and not one.discarded
