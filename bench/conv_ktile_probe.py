@@ -26,7 +26,7 @@ def timed(fn, iters=5, warm=2):
 def main():
     dev = "cuda"
     N, H, W, Cout = 256, 12, 160, int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    for cfg in (1128, 8128, 7256):
+    for cfg in (1128, 8128):
         row = {}
         for Cin in (64, 128, 256, 512):
             x = torch.randn(N, H, W, Cin, device=dev).to(torch.bfloat16)

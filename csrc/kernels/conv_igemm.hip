@@ -444,8 +444,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& p) {
       conv_store_tile_from_lds<BM, BN>(p, smem, OROWB, m0, n0, tid);
     }
   } else {
-    // tall per-wave tiles: rolled loop + accumulator rotation (see conv_glds_kernel: an unrolled epilogue of this
-    // size pushes acc[][j] into scratch, and a kernel with scratch runs 4-5x slower)
+    // tall per-wave tiles: rolled loop + accumulator rotation (an unrolled epilogue of this size pushes acc[][j]
+    // into scratch, and a kernel with scratch runs 4-5x slower)
 #pragma nounroll
     for (int j = 0; j < FM; ++j) {
       const int m = m0 + wm * TM + j * 16 + frow;
@@ -717,354 +717,6 @@ static int dispatch_patch(ConvArgs& a, hipStream_t stream) {
   }
 }
 
-// 256 zero bytes: the source of LDS-DMA lanes whose pixel lies outside the image
-__device__ __attribute__((aligned(256))) uint8_t dlamd_zero_page[256];
-
-// ---------------------------------------------------------------------------------------------------------
-// 3x3 stride-1 convolution of 64 input channels into (up to) 64 output channels with the WHOLE FILTER RESIDENT.
-//
-// On the quarter-scale maps of the detector (layer1: 2 M pixels per batch, K = 576) a tile of the patch kernel above
-// has ~1 us of MFMA work per wave and 18 dependent weight fetches from L2 in front of it - the kernel is bound by
-// those round trips (MFMA busy 0.21 - 0.25).  Here a persistent workgroup loads its share of the 72 KB filter
-// into registers once (a wave owns 32 output channels: 2 fragments x 18 k-steps = 144 registers) and walks over a
-// contiguous range of 16 x 16-pixel tiles:
-//   * the input patch of tile t + 1 is issued as LDS-DMA right after tile t's barrier and lands under tile t's
-//     MFMAs without touching a register; patches alternate between two LDS buffers, so a tile costs ONE barrier;
-//   * the inner loop is LDS fragment reads and MFMAs only (8 reads per 16 MFMAs) - no global load in it.
-// One 4-wave workgroup per CU, one wave per SIMD: the filter (144 registers), a 128 x 32 accumulator (64) and two
-// sets of eight pixel fragments (64) need more than the 256 registers a wave has at two waves per SIMD (the 8 x 16
-// tile form with two workgroups per CU compiles to 62 spilled registers and is not dispatched).
-// Measured on 25 detector pages (bench/conv64_probe.py): 0.240 ms against 0.270 ms for the 256-pixel patch kernel
-// with the general epilogue, 0.226 ms for the patch kernel with the same lean epilogue;
-// with one wave per SIMD a tile's phases (DMA issue, MFMAs, epilogue) still run back to back - 7.8 us per tile
-// against 1.9 us of MFMA time.
-template <int TH, int TW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TH * TW == 256 ? 1 : 2, TH * TW == 256 ? 1 : 2)))
-void conv3x3_c64_kernel(const ConvArgs p, const int tiles_total, const int tiles_per_wg) {
-  constexpr int NT = 256, WN = 2;
-  constexpr int TM = TH * TW / 2, TN = 32, FM = TM / 16, FN = 2;
-  constexpr int PH = TH + 2, PW = TW + 2;
-  constexpr int PER = (PH * PW * 128 + 4095) / 4096;   // LDS-DMA instructions per wave and patch (1 KiB each)
-  constexpr int PBYTES = PER * 4096;
-  static_assert((TH * TW == 256 || TH * TW == 128) && TW % 16 == 0 && NT == 256, "tile");
-  extern __shared__ __attribute__((aligned(1024))) char smem[];   // 2 patches, XOR-swizzled chunks
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid / WN, wn = wid % WN;
-  const int frow = lane & 15, fq = lane >> 4;
-  const int t0 = blockIdx.x * tiles_per_wg;
-  const int t1 = min(t0 + tiles_per_wg, tiles_total);
-  if (t0 >= t1) return;                              // uniform per workgroup
-  const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
-
-  // the filter: fragment order [N/16][K/32][64][8], K = tap * 64 + cin -> k-step index tap * 2 + ks
-  bf16x8 wreg[FN][18];
-  {
-    const bf16_t* wfp = p.wfrag + (long long)lane * 8;
-#pragma unroll
-    for (int i = 0; i < FN; ++i) {
-      const long long wt = (long long)min(wn * FN + i, p.n16 - 1) * p.k32 * 512;
-#pragma unroll
-      for (int s2 = 0; s2 < 18; ++s2) wreg[i][s2] = *reinterpret_cast<const bf16x8*>(wfp + wt + s2 * 512);
-    }
-  }
-
-  // patch staging by LDS-DMA: wave instruction k of wave w fills the 1 KiB [(4 k + w) * 1024, +1024) of the buffer,
-  // lane l its 16-byte slot l - pixel pp = (4 k + w) * 8 + (l >> 3), slot l & 7, which holds chunk slot ^ (pp & 7)
-  // (the swizzle is applied on the source side).  Pixels outside the image, and slots past the patch, read zeros.
-  const bf16_t* zero = reinterpret_cast<const bf16_t*>(dlamd_zero_page);
-  auto issue_patch = [&](int t, char* buf) {
-    const int tx = t % tiles_x;
-    const int r = t / tiles_x;
-    const int ty = r % tiles_y, b = r / tiles_y;
-    const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      const int pp = (k * 4 + wid) * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ (pp & 7);
-      const int pr = pp / PW, pc = pp - pr * PW;
-      const int y = iy0 + pr, x = ix0 + pc;
-      const bool ok = pp < PH * PW && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-      const bf16_t* src = ok ? p.x + ((long long)(b * p.H + y) * p.W + x) * p.x_cstride + c * 8 : zero;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(buf + (k * 4 + wid) * 1024), 16, 0, 0);
-    }
-  };
-
-  int pbase[FM];
-#pragma unroll
-  for (int j = 0; j < FM; ++j) {
-    const int lp = wm * TM + j * 16 + frow;
-    const int py = lp / TW, px = lp - py * TW;
-    pbase[j] = py * PW + px;
-  }
-
-  issue_patch(t0, smem);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  for (int t = t0; t < t1; ++t) {
-    char* buf = smem + ((t - t0) & 1) * PBYTES;
-    __syncthreads();          // patch t is complete; every wave is past its reads of patch t - 1 (the other buffer)
-    if (t + 1 < t1) issue_patch(t + 1, smem + ((t + 1 - t0) & 1) * PBYTES);
-
-    f32x4 acc[FN][FM];
-#pragma unroll
-    for (int i = 0; i < FN; ++i)
-#pragma unroll
-      for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // pixel fragments of k-step s + 1 are read while the MFMAs of step s run; the scheduling fences keep the
-    // compiler from hoisting more (fully unrolled, it otherwise pulls all 144 reads up front and spills)
-    bf16x8 xf[2][FM];
-    auto read_x = [&](int s2, bf16x8 (&dst)[FM]) {
-      const int tap = s2 >> 1, ks = s2 & 1;
-      const int dy = tap / 3, dx = tap - dy * 3;
-#pragma unroll
-      for (int j = 0; j < FM; ++j) {
-        const int pp = pbase[j] + dy * PW + dx;
-        dst[j] = *reinterpret_cast<const bf16x8*>(buf + pp * 128 + (((ks * 4 + fq) ^ (pp & 7)) << 4));
-      }
-    };
-    read_x(0, xf[0]);
-#pragma unroll
-    for (int s2 = 0; s2 < 18; ++s2) {
-      if (s2 + 1 < 18) read_x(s2 + 1, xf[(s2 + 1) & 1]);
-#pragma unroll
-      for (int i = 0; i < FN; ++i)
-#pragma unroll
-        for (int j = 0; j < FM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[i][s2], xf[s2 & 1][j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // this wave's share of patch t + 1 has had the whole tile to land; waiting HERE, before the output stores are
-    // issued, keeps those stores out of the wait (the counter covers loads and stores alike) - they drain under
-    // the next tile
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    // lean epilogue (host contract: plain bf16 store, bias, optional same-size residual, none / ReLU): with one wave
-    // per SIMD nothing overlaps epilogue instructions, and the general epilogue is thousands of them per tile
-    const int tx = t % tiles_x;
-    const int r = t / tiles_x;
-    const int ty = r % tiles_y, b = r / tiles_y;
-    bf16_t* yp = reinterpret_cast<bf16_t*>(p.y);
-    const bool relu = p.act == ACT_RELU;
-#pragma unroll
-    for (int i = 0; i < FN; ++i) {
-      const int n = wn * TN + i * 16 + fq * 4;
-      if (n >= p.Cout) continue;
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-      for (int j = 0; j < FM; ++j) {
-        const int lp = wm * TM + j * 16 + frow;
-        const int py = lp / TW, px = lp - py * TW;
-        const int oy = ty * TH + py, ox = tx * TW + px;
-        if (oy >= p.Ho || ox >= p.Wo) continue;
-        const long long m = ((long long)b * p.Ho + oy) * p.Wo + ox;
-        float v0 = acc[i][j][0] + bv[0], v1 = acc[i][j][1] + bv[1], v2 = acc[i][j][2] + bv[2], v3 = acc[i][j][3] + bv[3];
-        if (p.res_mode == 1) {
-          const u32x2 rr = *reinterpret_cast<const u32x2*>(p.res + m * p.res_cstride + n);
-          v0 += bf16_bits_to_f32(rr[0] & 0xffffu);
-          v1 += bf16_bits_to_f32(rr[0] >> 16);
-          v2 += bf16_bits_to_f32(rr[1] & 0xffffu);
-          v3 += bf16_bits_to_f32(rr[1] >> 16);
-        }
-        if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-        const bf16x4 o = {(bf16_t)v0, (bf16_t)v1, (bf16_t)v2, (bf16_t)v3};
-        *reinterpret_cast<bf16x4*>(yp + m * p.y_cstride + p.y_coff + n) = o;
-      }
-    }
-  }
-}
-
-// Host contract: 3x3, stride 1, pad 1, Cin == 64, Cout <= 64 and a multiple of 4 (one 64-channel tile); plain bf16
-// store (any channel stride / offset), bias, optional same-size residual, activation none or ReLU.
-template <int TH, int TW>
-static int launch_c64(ConvArgs& a, hipStream_t stream) {
-  constexpr int WGS_PER_CU = TH * TW == 256 ? 1 : 2;
-  if (a.Cin != 64 || a.Cout > 64 || (a.Cout & 3) || a.k32 < 18) return -2;
-  if (a.out_mode != 0 || a.y_f32 || a.res_mode > 1 || (a.act != ACT_NONE && a.act != ACT_RELU)) return -13;
-  a.tiles_n = 1;
-  const long long tiles = (long long)a.B * ((a.Ho + TH - 1) / TH) * ((a.Wo + TW - 1) / TW);
-  if (tiles <= 0 || tiles > 0x7fffffffLL) return -3;
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -5;
-    cus = prop.multiProcessorCount;
-  }
-  const long long slots = (long long)cus * WGS_PER_CU;
-  const int per = (int)((tiles + slots - 1) / slots);
-  const int grid = (int)((tiles + per - 1) / per);
-  constexpr size_t smem = (size_t)2 * (((TH + 2) * (TW + 2) * 128 + 4095) / 4096) * 4096;
-  auto kern = conv3x3_c64_kernel<TH, TW>;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return -2;
-    attr = true;
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, stream, a, (int)tiles, per);
-  return DLAMD_CHECK_LAUNCH();
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Big-tile convolution staged by LDS-DMA (global_load_lds_dwordx4): 256 pixels x BN channels per 8-wave workgroup.
-//   * 7.6 KB (BN = 256) or 11.4 KB (BN = 128) of L2 traffic per MFLOP-tile instead of 24 KB,
-//   * BOTH operands go global -> LDS without touching a VGPR (the registers hold a 128 x 64 accumulator per
-//     wave instead), issued one K-tile ahead so a whole K-tile of MFMAs (~2000 cycles) covers their latency,
-//   * the im2col gather is the DMA's per-lane SOURCE address; taps that fall outside the image read a zero page,
-//   * an LDS-DMA wave-instruction writes 1 KiB contiguously (lane l -> byte 16 l), so the XOR swizzle is applied
-//     on the source side: lane (row = l >> 3, slot = l & 7) fetches chunk slot ^ (row & 7) of its row.
-// One barrier per 64-deep K-tile: s_waitcnt vmcnt(0) (the DMA of tile t+1 has landed) + __syncthreads().
-// Measured (bench/conv_ktile_probe.py, profiles/06): the main loop runs at 1190-1310 TFLOP/s against 880-900 for
-// the 64 x 128 kernel, but with one 128 KB workgroup per CU nothing overlaps a tile's prologue and epilogue, so
-// at the K depths of this model (9-72 K-tiles) the whole launch only ties (K >= 36) or loses; a persistent
-// variant that prefetched the next tile under the epilogue did not change that.  Kept as explicit configs
-// (7256 / 7128) for deeper-K models; auto mode does not pick it.
-
-template <int BN, int WM, int WN, bool IS_1X1>
-__global__ __launch_bounds__(512) void conv_glds_kernel(const ConvArgs p) {
-  constexpr int BM = 256, ROWB = 128;
-  constexpr int TM = BM / WM, TN = BN / WN;
-  constexpr int FM = TM / 16, FN = TN / 16;
-  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
-  constexpr int PA = BM / 64, PB = BN / 64;          // DMA instructions per thread and K-tile (64 rows each)
-  static_assert(WM * WN == 8 && TM % 16 == 0 && TN % 16 == 0, "8 waves");
-  extern __shared__ __attribute__((aligned(1024))) char smem[];   // 2 stages x (pixels | weights)
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid / WN, wn = wid % WN;
-  const int frow = lane & 15, fq = lane >> 4;
-  const int tile = dlamd_xcd_remap(blockIdx.x, gridDim.x);
-  const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int nkt = p.K >> 6;
-
-  // loader role of this lane: row rp of every 64-row pass, 16-byte chunk ch of the 128-byte K row
-  const int rp = tid >> 3;
-  const int ch = (tid & 7) ^ (rp & 7);
-  const bf16_t* zero = reinterpret_cast<const bf16_t*>(dlamd_zero_page);
-
-  long long a_base[PA];
-  int a_hi0[PA], a_wi0[PA];
-#pragma unroll
-  for (int i = 0; i < PA; ++i) {
-    const int m = m0 + rp + 64 * i;
-    const bool ok = m < p.M;
-    const int mm = ok ? m : 0;
-    const int hw = p.Ho * p.Wo;
-    const int b = mm / hw, rem = mm - b * hw;
-    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-    a_hi0[i] = ok ? ho * p.sh - p.ph : -(1 << 28);      // rows past M fail the bounds test -> zero page
-    a_wi0[i] = wo * p.sw - p.pw;
-    a_base[i] = ((long long)(b * p.H + (ho * p.sh - p.ph)) * p.W + a_wi0[i]) * p.x_cstride + ch * 8;
-  }
-  const bf16_t* b_src[PB];
-#pragma unroll
-  for (int i = 0; i < PB; ++i) {
-    const int n = n0 + rp + 64 * i;
-    b_src[i] = n < p.Cout ? p.w + (long long)n * p.K + ch * 8 : nullptr;
-  }
-
-  auto issue_tile = [&](int kt, int stage) {
-    int dy = 0, dx = 0, cin0 = kt * 64;
-    if (!IS_1X1) {
-      const int tap = cin0 / p.Cin;
-      cin0 -= tap * p.Cin;
-      dy = tap / p.kw;
-      dx = tap - dy * p.kw;
-    }
-    const long long off = (long long)(dy * p.W + dx) * p.x_cstride + cin0;
-    char* sa = smem + stage * STAGE + wid * 1024;
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const bool v = (unsigned)(a_hi0[i] + dy) < (unsigned)p.H && (unsigned)(a_wi0[i] + dx) < (unsigned)p.W;
-      const bf16_t* src = v ? p.x + a_base[i] + off : zero;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sa + i * 64 * ROWB), 16, 0, 0);
-    }
-    char* sb = smem + stage * STAGE + A_BYTES + wid * 1024;
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      const bf16_t* src = b_src[i] ? b_src[i] + kt * 64 : zero;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sb + i * 64 * ROWB), 16, 0, 0);
-    }
-  };
-
-  f32x4 acc[FN][FM];
-#pragma unroll
-  for (int i = 0; i < FN; ++i)
-#pragma unroll
-    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  issue_tile(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int stage = kt & 1;
-    if (kt + 1 < nkt) issue_tile(kt + 1, stage ^ 1);
-    const char* Ab = smem + stage * STAGE;
-    const char* Bb = Ab + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 wf[FN], xf[FM];
-      const int chunk = ks * 4 + fq;
-#pragma unroll
-      for (int i = 0; i < FN; ++i) {
-        const int row = wn * TN + i * 16 + frow;
-        wf[i] = *reinterpret_cast<const bf16x8*>(Bb + row * ROWB + ((chunk ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < FM; ++j) {
-        const int row = wm * TM + j * 16 + frow;
-        xf[j] = *reinterpret_cast<const bf16x8*>(Ab + row * ROWB + ((chunk ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < FN; ++i)
-#pragma unroll
-        for (int j = 0; j < FM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile kt+1 has landed in the other stage
-    __syncthreads();                                      // ... for every wave, and stage kt is free to overwrite
-  }
-
-  // Epilogue as a ROLLED loop over the wave's pixel sub-tiles.  Unrolled, the fused epilogue is too large, the
-  // compiler then indexes acc[][j] in scratch memory - and a kernel that owns scratch ran 4-5x slower here
-  // whatever its main loop did (every big-tile variant with a non-zero ScratchSize, docs/KERNELS.md).
-  // So the loop always consumes acc[.][0] and then rotates the tiles down.
-#pragma nounroll
-  for (int j = 0; j < FM; ++j) {
-    const int m = m0 + wm * TM + j * 16 + frow;
-    if (m < p.M) conv_epilogue_pixel<FN, FM>(p, acc, 0, m, n0 + wn * TN, fq);
-#pragma unroll
-    for (int i = 0; i < FN; ++i)
-#pragma unroll
-      for (int jj = 0; jj + 1 < FM; ++jj) acc[i][jj] = acc[i][jj + 1];
-  }
-}
-
-template <int BN, int WM, int WN, bool IS_1X1>
-static int launch_glds(ConvArgs& a, hipStream_t stream) {
-  if (a.Cin % 64 != 0 || a.K % 64 != 0) return -16;        // a 64-deep K tile must lie inside one filter tap
-  a.tiles_m = (a.M + 255) / 256;
-  a.tiles_n = (a.Cout + BN - 1) / BN;
-  const size_t smem = 2 * (256 + BN) * 128;
-  auto kern = conv_glds_kernel<BN, WM, WN, IS_1X1>;
-  static bool set = false;
-  if (!set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return -2;
-    set = true;
-  }
-  long long grid = (long long)a.tiles_m * a.tiles_n;
-  if (grid <= 0 || grid > 0x7fffffffLL) return -3;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, a);
-  return DLAMD_CHECK_LAUNCH();
-}
-
 template <int BM, int BN, int WM, int WN, bool IS_1X1, bool B_DIRECT, int BKT>
 static int launch_impl(ConvArgs& a, hipStream_t stream) {
   a.tiles_m = (a.M + BM - 1) / BM;
@@ -1170,8 +822,6 @@ static int dispatch(ConvArgs& a, hipStream_t stream, int cfg) {
       if (!a.wfrag) return -14;
       return launch_impl<32, 32, 2, 2, IS_1X1, true, 128>(a, stream);
     case 8128: return launch_persistent<64, 128, 1, 4, IS_1X1>(a, stream);   // persistent 64 x 128
-    case 7256: return launch_glds<256, 2, 4, IS_1X1>(a, stream);     // 256 x 256, LDS-DMA staged, 8 waves
-    case 7128: return launch_glds<128, 4, 2, IS_1X1>(a, stream);     // 256 x 128
     // Bigger REGISTER-staged tiles with direct weights (128x128, 256x128, 128x256 as 1x4 waves) were measured
     // twice and dropped (profiles/06_conv_tile_sweep.txt): first 4-5x slower because their unrolled epilogue put
     // the accumulators in scratch, then - scratch-free, rolled epilogue - still 1.25x / 2x / 1.6x slower than
@@ -1263,10 +913,6 @@ extern "C" int dlamd_conv2d(const void* x, const void* w, const float* bias, con
     return sh == 1 ? dispatch_patch<1, 64, 2, 2>(a, stream) : dispatch_patch<2, 64, 2, 2>(a, stream);
   if (patch_ok && cfg == 3464)      // 256 pixels x 64 channels, 8 waves
     return sh == 1 ? dispatch_patch256<1, 64>(a, stream) : dispatch_patch256<2, 64>(a, stream);
-  if (cfg == 3664) {                // resident filter: 3x3 stride 1, 64 -> <= 64 channels
-    if (!(patch_ok && sh == 1 && Cin == 64 && Cout <= 64)) return -13;
-    return launch_c64<16, 16>(a, stream);
-  }
   if (patch_ok && cfg == 3428)      // 256 pixels x 128 channels, 8 waves
     return sh == 1 ? dispatch_patch256<1, 128>(a, stream) : dispatch_patch256<2, 128>(a, stream);
   // Auto mode, stride 1 (bench/conv64_probe.py, 25 detector pages): the 64-channel tile as 2 x 2 waves, where every
@@ -1275,17 +921,7 @@ extern "C" int dlamd_conv2d(const void* x, const void* w, const float* bias, con
   // direct-weight tile by 5-7 % on the 128-channel layers with shallow K; on the quarter-scale maps the 256-pixel
   // 8-wave tile halves the weight traffic once more (layer1 0.270 ms, head 0.667).
   if (patch_ok && cfg == 0 && sh == 1 && (Cout <= 64 || (Cout <= 128 && Cin <= 128))) {
-    if (Cout <= 64 && (long long)B * a.Ho * a.Wo >= 1000000 && a.Ho >= 16) {
-      // 64 -> 64 on the quarter-scale maps: the resident-filter kernel runs 0.240 ms on 25 pages (patch kernel:
-      // 0.226), and it owns its CUs (one wave per SIMD with the whole register file), so in the two-stream
-      // pipeline the other stream's kernels cannot share them: 672 us per call there, bench.py unchanged within
-      // noise (961 against 956 pages/s).  Opt-in: DLAMD_CONV_C64=1.
-      static const bool c64 = [] { const char* e = getenv("DLAMD_CONV_C64"); return e && e[0] == '1'; }();
-      if (c64 && Cin == 64 && (Cout & 3) == 0 && a.out_mode == 0 && !a.y_f32 && a.res_mode <= 1 &&
-          (a.act == ACT_NONE || a.act == ACT_RELU))
-        return launch_c64<16, 16>(a, stream);
-      return dispatch_patch256<1, 64>(a, stream);
-    }
+    if (Cout <= 64 && (long long)B * a.Ho * a.Wo >= 1000000 && a.Ho >= 16) return dispatch_patch256<1, 64>(a, stream);
     return dispatch_patch<1, 64, 2, 2>(a, stream);
   }
   if (patch_ok && ((cfg == 0 && Cout <= 64 && sh == 1) || cfg == 3064 || cfg == 3128)) {
@@ -1294,12 +930,6 @@ extern "C" int dlamd_conv2d(const void* x, const void* w, const float* bias, con
     return wide ? dispatch_patch<2, 128, 2, 2>(a, stream) : dispatch_patch<2, 64, 4, 1>(a, stream);
   }
   if (cfg == 3064 || cfg == 3128) return -13;
-  // Deep-K, 256-multiple-Cout 3x3 layers (CRNN c4 / c5): the LDS-DMA 256 x 256 kernel wins by 2-5 % (sweep 4 in
-  // profiles/06_conv_tile_sweep.txt); everywhere else its un-overlapped prologue / epilogue loses.
-  static const bool glds_auto = getenv("DLAMD_CONV_GLDS") != nullptr && atoi(getenv("DLAMD_CONV_GLDS")) != 0;
-  if (glds_auto && cfg == 0 && Cin % 64 == 0 && Cout % 256 == 0 && a.K >= 36 * 64 && kh == 3 && kw == 3 &&
-      (long long)((a.M + 255) / 256) * (Cout / 256) >= 1024)
-    cfg = 7256;
   if (cfg == 3900) cfg = 0;
   const bool is1x1 = (kh == 1 && kw == 1 && ph == 0 && pw == 0);
   return is1x1 ? dispatch<true>(a, stream, cfg) : dispatch<false>(a, stream, cfg);

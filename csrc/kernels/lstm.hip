@@ -143,376 +143,11 @@ __global__ __launch_bounds__(256) void lstm_bidir_kernel(const bf16_t* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// v2 (throughput shape): 8 waves per workgroup and ST x 16 sequences per workgroup.
-// The recurrence is bound by streaming W_hh (2*H*4H bytes per direction) from L2 once per step per
-// workgroup, so (a) ST sequence tiles share every W fragment (half / quarter the workgroups and the
-// L2 traffic for the same batch), (b) 8 waves keep twice as many loads in flight per CU, and (c) the
-// K loop is outermost with the next K-group's W fragments prefetched while the current group's
-// MFMAs run (W does not depend on h, so the prefetch also wraps across the step boundary).
-template <int H, int ST>
-__global__ __launch_bounds__(512) void lstm_bidir_kernel2(const bf16_t* __restrict__ xproj, const bf16_t* __restrict__ wfrag,
-                                                          const int* __restrict__ lens,
-                                                          const long long* __restrict__ row_off,
-                                                          const int* __restrict__ tcap, const int* __restrict__ perm,
-                                                          bf16_t* __restrict__ y, int N, int T, int ndir) {
-  constexpr int G = 4 * H;
-  constexpr int NW = 8;
-  constexpr int TILES = G / 16 / NW;
-  constexpr int KS = H / 32;
-  constexpr int HROW = H * 2 + 16;
-  constexpr int SEQ = 16 * ST;
-  static_assert(TILES % 4 == 0, "a lane needs 4 consecutive tiles per hidden-unit group");
-  extern __shared__ __attribute__((aligned(16))) char hbuf_dyn[];
-  char* hb0 = hbuf_dyn;
-  char* hb1 = hbuf_dyn + SEQ * HROW;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int seq_l = lane & 15, fq = lane >> 4;
-  const int dir = blockIdx.y;
-  const long long xrow = (long long)ndir * G;
-  const long long yrow = (long long)ndir * H;
-
-  int len[ST], cap[ST];
-  bool ok[ST];
-  const bf16_t* xp[ST];
-  bf16_t* yp[ST];
-  int maxlen = 0;
-#pragma unroll
-  for (int st = 0; st < ST; ++st) {
-    const int slot = blockIdx.x * SEQ + st * 16 + seq_l;
-    ok[st] = slot < N;
-    const int n = ok[st] ? (perm ? perm[slot] : slot) : 0;
-    cap[st] = ok[st] ? (tcap ? tcap[n] : T) : 0;
-    len[st] = ok[st] ? (lens ? min(lens[n], cap[st]) : cap[st]) : 0;
-    const long long row0 = ok[st] ? (row_off ? row_off[n] : (long long)n * T) : 0;
-    xp[st] = xproj + row0 * xrow + (long long)dir * G + (wave * TILES) * 16 + fq * 4;
-    yp[st] = y + row0 * yrow + (long long)dir * H;
-    maxlen = max(maxlen, len[st]);
-  }
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
-
-  for (int i = tid; i < 2 * SEQ * HROW / 4; i += 512) reinterpret_cast<uint32_t*>(hbuf_dyn)[i] = 0u;
-  __syncthreads();
-
-  const bf16_t* wf = wfrag + (long long)dir * G * H + (long long)wave * TILES * KS * 64 * 8 + lane * 8;
-  float cst[TILES][ST];
-#pragma unroll
-  for (int i = 0; i < TILES; ++i)
-#pragma unroll
-    for (int st = 0; st < ST; ++st) cst[i][st] = 0.f;
-
-  bf16x8 wa[TILES], wb[TILES];
-#pragma unroll
-  for (int i = 0; i < TILES; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(wf + (long long)(i * KS) * 64 * 8);
-  // gate pre-activations of the CURRENT step (loaded one step ahead: they come from HBM)
-  u32x2 xc[TILES][ST], xn[TILES][ST];
-#pragma unroll
-  for (int st = 0; st < ST; ++st) {
-    const int t0 = dir == 0 ? 0 : (len[st] - 1);
-#pragma unroll
-    for (int i = 0; i < TILES; ++i) {
-      xc[i][st] = u32x2{0u, 0u};
-      if (len[st] > 0) xc[i][st] = *reinterpret_cast<const u32x2*>(xp[st] + (long long)t0 * xrow + i * 16);
-    }
-  }
-
-  for (int step = 0; step < maxlen; ++step) {
-    const char* hc = (step & 1) ? hb1 : hb0;
-    char* hn = (step & 1) ? hb0 : hb1;
-    const bf16_t* wfs = wf;          // see v1: keep the W loads inside the step loop
-    asm volatile("" : "+v"(wfs));
-    f32x4 acc[TILES][ST];
-    bool act[ST];
-    int tt[ST];
-#pragma unroll
-    for (int st = 0; st < ST; ++st) {
-      act[st] = step < len[st];
-      tt[st] = dir == 0 ? step : (len[st] - 1 - step);
-#pragma unroll
-      for (int i = 0; i < TILES; ++i) acc[i][st] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int ks = 0; ks < KS; ks += 2) {
-      // even group computes from wa while wb (ks + 1) is in flight, and vice versa
-#pragma unroll
-      for (int i = 0; i < TILES; ++i) wb[i] = *reinterpret_cast<const bf16x8*>(wfs + (long long)(i * KS + ks + 1) * 64 * 8);
-      {
-        bf16x8 hf[ST];
-#pragma unroll
-        for (int st = 0; st < ST; ++st)
-          hf[st] = *reinterpret_cast<const bf16x8*>(hc + (st * 16 + seq_l) * HROW + ks * 64 + fq * 16);
-#pragma unroll
-        for (int i = 0; i < TILES; ++i)
-#pragma unroll
-          for (int st = 0; st < ST; ++st) acc[i][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[i], hf[st], acc[i][st], 0, 0, 0);
-      }
-      const int kn = (ks + 2) % KS;  // wraps to the first group of the next step
-#pragma unroll
-      for (int i = 0; i < TILES; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(wfs + (long long)(i * KS + kn) * 64 * 8);
-      if (ks == KS - 2) {
-        // last loads of the step: next step's pre-activations.  Issued after every W load of this step so
-        // that (in-order vmcnt) no W wait of this step has to cover their HBM latency.
-#pragma unroll
-        for (int st = 0; st < ST; ++st) {
-          const bool nact = step + 1 < len[st];
-          const int tn = dir == 0 ? step + 1 : (len[st] - 2 - step);
-#pragma unroll
-          for (int i = 0; i < TILES; ++i) {
-            xn[i][st] = u32x2{0u, 0u};
-            if (nact) xn[i][st] = *reinterpret_cast<const u32x2*>(xp[st] + (long long)tn * xrow + i * 16);
-          }
-        }
-      }
-      {
-        bf16x8 hf[ST];
-#pragma unroll
-        for (int st = 0; st < ST; ++st)
-          hf[st] = *reinterpret_cast<const bf16x8*>(hc + (st * 16 + seq_l) * HROW + (ks + 1) * 64 + fq * 16);
-#pragma unroll
-        for (int i = 0; i < TILES; ++i)
-#pragma unroll
-          for (int st = 0; st < ST; ++st) acc[i][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[i], hf[st], acc[i][st], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int st = 0; st < ST; ++st) {
-#pragma unroll
-      for (int a = 0; a < TILES / 4; ++a) {
-        bf16x4 hv;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int i = a * 4 + q;
-          const u32x2 raw = xc[i][st];
-          float ig = dl_sigmoid(acc[i][st][0] + bf16_bits_to_f32(raw[0] & 0xffffu));
-          float fg = dl_sigmoid(acc[i][st][1] + bf16_bits_to_f32(raw[0] >> 16));
-          float gg = dl_tanh(acc[i][st][2] + bf16_bits_to_f32(raw[1] & 0xffffu));
-          float og = dl_sigmoid(acc[i][st][3] + bf16_bits_to_f32(raw[1] >> 16));
-          float c = fg * cst[i][st] + ig * gg;
-          float h = og * dl_tanh(c);
-          if (act[st]) cst[i][st] = c;
-          hv[q] = (bf16_t)h;
-        }
-        const int unit = (wave * (TILES / 4) + a) * 16 + fq * 4;
-        const int hoff = (st * 16 + seq_l) * HROW + unit * 2;
-        if (act[st]) {
-          *reinterpret_cast<bf16x4*>(hn + hoff) = hv;
-          *reinterpret_cast<bf16x4*>(yp[st] + (long long)tt[st] * yrow + unit) = hv;
-        } else {
-          *reinterpret_cast<u32x2*>(hn + hoff) = *reinterpret_cast<const u32x2*>(hc + hoff);
-        }
-      }
-    }
-#pragma unroll
-    for (int st = 0; st < ST; ++st)
-#pragma unroll
-      for (int i = 0; i < TILES; ++i) xc[i][st] = xn[i][st];
-    __syncthreads();
-  }
-#pragma unroll
-  for (int st = 0; st < ST; ++st) {
-    if (!ok[st]) continue;
-    for (int t = len[st]; t < cap[st]; ++t)
-#pragma unroll
-      for (int a = 0; a < TILES / 4; ++a) {
-        const int unit = (wave * (TILES / 4) + a) * 16 + fq * 4;
-        *reinterpret_cast<u32x2*>(yp[st] + (long long)t * yrow + unit) = u32x2{0u, 0u};
-      }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// v3 (W_hh half resident): v2x16 runs at the L2 -> CU bandwidth - every step a workgroup pulls the whole
-// 2*H*4H = 512 KB W_hh slice of its direction through L2 at the ~70 GB/s a CU gets from L2
-// (MI355X_MICROARCH "Indexed rows"), i.e. ~7.5 us per step.  A CU cannot hold 512 KB, but it can hold half:
-//   K-steps 0,1  -> registers   (8 waves x 64 lanes x 64 VGPRs = 128 KB)
-//   K-steps 2,3  -> LDS         (128 KB, read back as conflict-free contiguous ds_read_b128)
-//   K-steps 4..7 -> streamed from L2 as before (256 KB per step), two K-steps in flight
-// The resident K-steps are computed first, so the streamed fragments (issued at the end of the previous
-// step) have the whole gate math + barrier + resident MFMAs to arrive.
-template <int H>
-__global__ __launch_bounds__(512) void lstm_bidir_kernel3(const bf16_t* __restrict__ xproj, const bf16_t* __restrict__ wfrag,
-                                                          const int* __restrict__ lens,
-                                                          const long long* __restrict__ row_off,
-                                                          const int* __restrict__ tcap, const int* __restrict__ perm,
-                                                          bf16_t* __restrict__ y, int N, int T, int ndir) {
-  constexpr int G = 4 * H;
-  constexpr int NW = 8;
-  constexpr int TILES = G / 16 / NW;
-  constexpr int KS = H / 32;
-  constexpr int HROW = H * 2 + 16;
-  constexpr int KR = 2, KL = 2;                 // K-steps resident in registers / in LDS
-  static_assert(KS == 8 && TILES == 8, "H = 256");
-  extern __shared__ __attribute__((aligned(16))) char smem3[];
-  char* hb0 = smem3;
-  char* hb1 = smem3 + 16 * HROW;
-  char* wl = smem3 + 2 * 16 * HROW;             // [wave][KL][TILES][64 lanes] x 16 B
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int seq_l = lane & 15, fq = lane >> 4;
-  const int dir = blockIdx.y;
-  const long long xrow = (long long)ndir * G;
-  const long long yrow = (long long)ndir * H;
-
-  const int slot = blockIdx.x * 16 + seq_l;
-  const bool ok = slot < N;
-  const int n = ok ? (perm ? perm[slot] : slot) : 0;
-  const int cap = ok ? (tcap ? tcap[n] : T) : 0;
-  const int len = ok ? (lens ? min(lens[n], cap) : cap) : 0;
-  const long long row0 = ok ? (row_off ? row_off[n] : (long long)n * T) : 0;
-  const bf16_t* xp = xproj + row0 * xrow + (long long)dir * G + (wave * TILES) * 16 + fq * 4;
-  bf16_t* yp = y + row0 * yrow + (long long)dir * H;
-  int maxlen = len;
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
-
-  for (int i = tid; i < 2 * 16 * HROW / 4; i += 512) reinterpret_cast<uint32_t*>(smem3)[i] = 0u;
-
-  const bf16_t* wf = wfrag + (long long)dir * G * H + (long long)wave * TILES * KS * 64 * 8 + lane * 8;
-  // resident fragments
-  bf16x8 wr[KR][TILES];
-#pragma unroll
-  for (int k = 0; k < KR; ++k)
-#pragma unroll
-    for (int i = 0; i < TILES; ++i) wr[k][i] = *reinterpret_cast<const bf16x8*>(wf + (long long)(i * KS + k) * 64 * 8);
-  char* wlw = wl + ((wave * KL * TILES) * 64 + lane) * 16;
-#pragma unroll
-  for (int k = 0; k < KL; ++k)
-#pragma unroll
-    for (int i = 0; i < TILES; ++i)
-      *reinterpret_cast<bf16x8*>(wlw + (k * TILES + i) * 1024) =
-          *reinterpret_cast<const bf16x8*>(wf + (long long)(i * KS + KR + k) * 64 * 8);
-  __syncthreads();
-
-  float cst[TILES];
-#pragma unroll
-  for (int i = 0; i < TILES; ++i) cst[i] = 0.f;
-
-  // streamed fragments: wa holds K-step 4 then 6, wb holds 5 then 7
-  bf16x8 wa[TILES], wb[TILES];
-#pragma unroll
-  for (int i = 0; i < TILES; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(wf + (long long)(i * KS + 4) * 64 * 8);
-#pragma unroll
-  for (int i = 0; i < TILES; ++i) wb[i] = *reinterpret_cast<const bf16x8*>(wf + (long long)(i * KS + 5) * 64 * 8);
-  u32x2 xc[TILES];
-  {
-    const int t0 = dir == 0 ? 0 : (len - 1);
-#pragma unroll
-    for (int i = 0; i < TILES; ++i) {
-      xc[i] = u32x2{0u, 0u};
-      if (len > 0) xc[i] = *reinterpret_cast<const u32x2*>(xp + (long long)t0 * xrow + i * 16);
-    }
-  }
-
-  for (int step = 0; step < maxlen; ++step) {
-    const char* hc = ((step & 1) ? hb1 : hb0) + seq_l * HROW + fq * 16;
-    char* hn = (step & 1) ? hb0 : hb1;
-    const bf16_t* wfs = wf;          // keep the streamed W loads inside the step loop (see v1)
-    asm volatile("" : "+v"(wfs));
-    const bool act = step < len;
-    const int tt = dir == 0 ? step : (len - 1 - step);
-    f32x4 acc[TILES];
-#pragma unroll
-    for (int i = 0; i < TILES; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // ---- resident K-steps: registers
-#pragma unroll
-    for (int k = 0; k < KR; ++k) {
-      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hc + k * 64);
-#pragma unroll
-      for (int i = 0; i < TILES; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[k][i], hf, acc[i], 0, 0, 0);
-    }
-    // ---- resident K-steps: LDS
-#pragma unroll
-    for (int k = 0; k < KL; ++k) {
-      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hc + (KR + k) * 64);
-#pragma unroll
-      for (int i = 0; i < TILES; ++i) {
-        const bf16x8 w = *reinterpret_cast<const bf16x8*>(wlw + (k * TILES + i) * 1024);
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, hf, acc[i], 0, 0, 0);
-      }
-    }
-    // ---- streamed K-steps 4..7
-    {
-      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hc + 4 * 64);
-#pragma unroll
-      for (int i = 0; i < TILES; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[i], hf, acc[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < TILES; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(wfs + (long long)(i * KS + 6) * 64 * 8);
-    }
-    {
-      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hc + 5 * 64);
-#pragma unroll
-      for (int i = 0; i < TILES; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[i], hf, acc[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < TILES; ++i) wb[i] = *reinterpret_cast<const bf16x8*>(wfs + (long long)(i * KS + 7) * 64 * 8);
-    }
-    {
-      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hc + 6 * 64);
-#pragma unroll
-      for (int i = 0; i < TILES; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[i], hf, acc[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < TILES; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(wfs + (long long)(i * KS + 4) * 64 * 8);
-    }
-    {
-      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hc + 7 * 64);
-#pragma unroll
-      for (int i = 0; i < TILES; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[i], hf, acc[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < TILES; ++i) wb[i] = *reinterpret_cast<const bf16x8*>(wfs + (long long)(i * KS + 5) * 64 * 8);
-    }
-    // ---- gates
-    const char* hcr = ((step & 1) ? hb1 : hb0);
-#pragma unroll
-    for (int a = 0; a < TILES / 4; ++a) {
-      bf16x4 hv;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = a * 4 + q;
-        const u32x2 raw = xc[i];
-        float ig = dl_sigmoid(acc[i][0] + bf16_bits_to_f32(raw[0] & 0xffffu));
-        float fg = dl_sigmoid(acc[i][1] + bf16_bits_to_f32(raw[0] >> 16));
-        float gg = dl_tanh(acc[i][2] + bf16_bits_to_f32(raw[1] & 0xffffu));
-        float og = dl_sigmoid(acc[i][3] + bf16_bits_to_f32(raw[1] >> 16));
-        float c = fg * cst[i] + ig * gg;
-        float h = og * dl_tanh(c);
-        if (act) cst[i] = c;
-        hv[q] = (bf16_t)h;
-      }
-      const int unit = (wave * (TILES / 4) + a) * 16 + fq * 4;
-      const int hoff = seq_l * HROW + unit * 2;
-      if (act) {
-        *reinterpret_cast<bf16x4*>(hn + hoff) = hv;
-        *reinterpret_cast<bf16x4*>(yp + (long long)tt * yrow + unit) = hv;
-      } else {
-        *reinterpret_cast<u32x2*>(hn + hoff) = *reinterpret_cast<const u32x2*>(hcr + hoff);
-      }
-    }
-    {
-      // next step's pre-activations (HBM), straight into xc now that the gates have consumed it: the load has
-      // the whole MFMA phase of the next step to land, and sits behind every W load that step waits on first
-      const bool nact = step + 1 < len;
-      const int tn = dir == 0 ? step + 1 : (len - 2 - step);
-#pragma unroll
-      for (int i = 0; i < TILES; ++i) {
-        xc[i] = u32x2{0u, 0u};
-        if (nact) xc[i] = *reinterpret_cast<const u32x2*>(xp + (long long)tn * xrow + i * 16);
-      }
-    }
-    __syncthreads();
-  }
-  if (ok) {
-    for (int t = len; t < cap; ++t)
-#pragma unroll
-      for (int a = 0; a < TILES / 4; ++a) {
-        const int unit = (wave * (TILES / 4) + a) * 16 + fq * 4;
-        *reinterpret_cast<u32x2*>(yp + (long long)t * yrow + unit) = u32x2{0u, 0u};
-      }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// v4 (W_hh 7/8 resident): v3 still pulls 256 KB of W_hh per step through L2 at the ~70 GB/s one CU gets, 3.6 us of
-// its 4.9 us step.  The register file of a CU is 512 KB: with 8 waves (2 per SIMD) a lane may keep 256 registers,
+// v4 (W_hh 7/8 resident, the H = 256 kernel): a workgroup that streams its direction's whole 2*H*4H = 512 KB W_hh
+// slice through L2 every step runs at the ~70 GB/s one CU gets from L2, ~7.5 us per step; with half of it resident
+// (two K-steps in registers, two in LDS) 4.9 us, 3.6 of them the streamed half.  (Both forms existed as kernels and
+// lost to this one at every batch size measured, bench/lstm_bench.py; they are gone.)
+// The register file of a CU is 512 KB: with 8 waves (2 per SIMD) a lane may keep 256 registers,
 // so KR = 5 K-steps of fragments (160 registers) live there, 2 more in LDS, and only ONE K-step (64 KB, 0.9 us)
 // is streamed per step - issued right after its use, it has the rest of the step and the next step's resident
 // MFMAs... to land.  To make room the accumulators start from the input projection (no separate copy of it is
@@ -746,38 +381,6 @@ static int launch_lstm4(const void* xproj, const void* wfrag, const void* lens, 
   return DLAMD_CHECK_LAUNCH();
 }
 
-static int launch_lstm3(const void* xproj, const void* wfrag, const void* lens, const void* row_off, const void* tcap,
-                        const void* perm, void* y, int N, int T, int ndir, hipStream_t stream) {
-  constexpr int H = 256;
-  const size_t smem = 2 * 16 * (H * 2 + 16) + 8 * 2 * 8 * 1024;      // h double buffer + 128 KB of W_hh
-  auto k = lstm_bidir_kernel3<H>;
-  static bool set = false;
-  if (!set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return -5;
-    set = true;
-  }
-  dim3 grid((N + 15) / 16, ndir);
-  hipLaunchKernelGGL(k, grid, dim3(512), smem, stream, (const bf16_t*)xproj, (const bf16_t*)wfrag, (const int*)lens,
-                     (const long long*)row_off, (const int*)tcap, (const int*)perm, (bf16_t*)y, N, T, ndir);
-  return DLAMD_CHECK_LAUNCH();
-}
-
-template <int H, int ST>
-static int launch_lstm2(const void* xproj, const void* wfrag, const void* lens, const void* row_off, const void* tcap,
-                        const void* perm, void* y, int N, int T, int ndir, hipStream_t stream) {
-  constexpr int SEQ = 16 * ST;
-  const size_t smem = 2 * SEQ * (H * 2 + 16);
-  auto k = lstm_bidir_kernel2<H, ST>;
-  if (smem > 65536 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-    return -5;
-  dim3 grid((N + SEQ - 1) / SEQ, ndir);
-  hipLaunchKernelGGL(k, grid, dim3(512), smem, stream, (const bf16_t*)xproj, (const bf16_t*)wfrag, (const int*)lens,
-                     (const long long*)row_off, (const int*)tcap, (const int*)perm, (bf16_t*)y, N, T, ndir);
-  return DLAMD_CHECK_LAUNCH();
-}
-
 // xproj: [N, T, ndir*4H] bf16 with gate columns in the permuted order (see
 // ops/lstm.py: lstm_gate_permutation); wfrag: fragment-ordered W_hh per direction.
 static int g_variant = -1;
@@ -796,26 +399,13 @@ extern "C" int dlamd_lstm_bidir(const void* xproj, const void* wfrag, const void
   if (ndir < 1 || ndir > 2) return -1;
   if ((row_off == nullptr) != (tcap == nullptr)) return -3;
   if (row_off && !lens) return -4;
-  // Shape selection: v1 (4 waves x 16 sequences) minimises latency for small batches; v2 (8 waves,
-  // 32 sequences) halves W_hh traffic per sequence once there are enough sequences to fill CUs anyway.
-  // DLAMD_LSTM_VARIANT (benchmarks only): 1 = v1, 2 = v2 with 16 sequences, 3 = v2 with 32 sequences.
-  // Measured on MI355X (us per step, H=256, both directions): N=970: v1 10.5, v2x16 7.5, v2x32 10.0;
-  // N=4000: v2x16 16.4, v2x32 13.1 -> 8-wave kernel everywhere, 32 sequences once CUs are oversubscribed.
+  // H = 256 (the recogniser): v4.  With 6 of 8 K-steps resident (4 in registers, 2 in LDS, 240 VGPRs, no spills) it
+  // runs 3.74 us/step at N = 1075; with 5 in registers the allocator spills four fragments and the reloads cost what
+  // the streaming saved (4.74 us/step), so auto picks KR = 4.  DLAMD_LSTM_VARIANT (benchmarks): 1 = the generic
+  // 4-wave kernel below, 5 = v4 with KR = 5.
   const int var = variant_env();
-  // v3 (half of W_hh resident in registers + LDS) beats both v2 shapes at every batch size measured:
-  // N=1075: 4.94 us/step vs 7.23 (v2x16); N=4000: 10.0 vs 12.65 (v2x32)  [bench/lstm_bench.py]; small batches are
-  // pure step latency, where v3 also wins (v1: ~10 us/step)
-  // v4 with 6 of 8 K-steps resident (4 in registers, 2 in LDS, 240 VGPRs, no spills): 3.74 us/step at N=1075 against
-  // 4.83 for v3; with 5 in registers the allocator spills four fragments and the reloads cost what the streaming saved
-  // (4.74 us/step), so auto picks KR = 4
   if (H == 256 && var == 5) return launch_lstm4<5>(xproj, wfrag, lens, row_off, tcap, perm, y, N, T, ndir, stream);
-  if (H == 256 && (var == 6 || var == 0)) return launch_lstm4<4>(xproj, wfrag, lens, row_off, tcap, perm, y, N, T, ndir, stream);
-  if (H == 256 && var == 4)
-    return launch_lstm3(xproj, wfrag, lens, row_off, tcap, perm, y, N, T, ndir, stream);
-  if (H == 256 && (var == 3 || (var == 0 && N >= 3072)))
-    return launch_lstm2<256, 2>(xproj, wfrag, lens, row_off, tcap, perm, y, N, T, ndir, stream);
-  if (H == 256 && (var == 2 || (var == 0 && N >= 64)))
-    return launch_lstm2<256, 1>(xproj, wfrag, lens, row_off, tcap, perm, y, N, T, ndir, stream);
+  if (H == 256 && var != 1) return launch_lstm4<4>(xproj, wfrag, lens, row_off, tcap, perm, y, N, T, ndir, stream);
   dim3 grid((N + 15) / 16, ndir);
   if (H == 256)
     hipLaunchKernelGGL(lstm_bidir_kernel<256>, grid, dim3(256), 0, stream, (const bf16_t*)xproj, (const bf16_t*)wfrag,

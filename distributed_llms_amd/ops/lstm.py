@@ -163,5 +163,5 @@ def lstm_layer_ragged(x: torch.Tensor, p: PackedLSTM, lay: RaggedLayout) -> torc
 
 
 def set_kernel_variant(variant: int) -> None:
-    """Tests / benchmarks: force a recurrence kernel (0 automatic, 1 v1, 2 v2x16, 3 v2x32, 4 v3 half-resident W_hh)."""
+    """Tests / benchmarks: force a recurrence kernel (0 automatic, 1 the generic 4-wave kernel, 5 v4 with 7 / 8 of W_hh resident)."""
     _loader.lib().dlamd_lstm_set_variant(int(variant))

@@ -172,6 +172,17 @@ TRAIN_FONTS = ("DejaVuSans.ttf", "DejaVuSans-Bold.ttf", "DejaVuSans-Oblique.ttf"
                "DejaVuSerif-Italic.ttf", "DejaVuSansMono.ttf", "DejaVuSansMono-Bold.ttf", "STIXGeneral.ttf",
                "STIXGeneralBol.ttf", "STIXGeneralItalic.ttf", "cmr10.ttf", "cmtt10.ttf", "cmb10.ttf")
 HELD_OUT_FONTS = ("Lato-Regular.ttf", "Lato-Bold.ttf", "Lato-Italic.ttf", "cmss10.ttf")   # never rendered in training
+# Cyrillic and Greek exist in three families here (DejaVu, STIX, Lato).  Pages in those alphabets are trained on DejaVu
+# and on Lato cuts that are NOT in ``HELD_OUT_FONTS`` (Latin training never draws any Lato file), and evaluated on the
+# STIX family - never drawn in these alphabets - plus the three held-out Lato cuts.  Lato is in the training side
+# because DejaVu's Greek is the odd one out (a round nu; nearly every text face draws nu pointed like a v).
+SCRIPT_TRAIN_FONTS = ("DejaVuSans.ttf", "DejaVuSans-Bold.ttf", "DejaVuSans-Oblique.ttf", "DejaVuSans-BoldOblique.ttf",
+                      "DejaVuSerif.ttf", "DejaVuSerif-Bold.ttf", "DejaVuSerif-Italic.ttf", "DejaVuSerif-BoldItalic.ttf",
+                      "DejaVuSansMono.ttf", "DejaVuSansMono-Bold.ttf", "Lato-Light.ttf", "Lato-Medium.ttf",
+                      "Lato-Semibold.ttf", "Lato-Heavy.ttf", "Lato-LightItalic.ttf", "Lato-MediumItalic.ttf",
+                      "Lato-SemiboldItalic.ttf", "Lato-HeavyItalic.ttf")
+SCRIPT_HELD_OUT_FONTS = ("STIXGeneral.ttf", "STIXGeneralBol.ttf", "STIXGeneralItalic.ttf", "STIXGeneralBolIta.ttf",
+                         "Lato-Regular.ttf", "Lato-Bold.ttf", "Lato-Italic.ttf")
 # the Computer Modern files carry TeX encodings: these code points show other glyphs there
 _CM_UNSAFE = set('<>\\_{|}"~^`')
 _FONT_PATHS = {}
@@ -380,7 +391,11 @@ def render_layout_page(seed: int, size: Tuple[int, int] = A4_300DPI, layout: Opt
     # headings: the bold sibling where one exists, else the same face larger
     bold_name = {"DejaVuSans.ttf": "DejaVuSans-Bold.ttf", "DejaVuSerif.ttf": "DejaVuSerif-Bold.ttf",
                  "DejaVuSansMono.ttf": "DejaVuSansMono-Bold.ttf", "STIXGeneral.ttf": "STIXGeneralBol.ttf",
-                 "Lato-Regular.ttf": "Lato-Bold.ttf", "cmr10.ttf": "cmb10.ttf"}.get(fname, fname)
+                 "Lato-Regular.ttf": "Lato-Bold.ttf", "cmr10.ttf": "cmb10.ttf", "Lato-Light.ttf": "Lato-Semibold.ttf",
+                 "Lato-Medium.ttf": "Lato-Heavy.ttf", "Lato-LightItalic.ttf": "Lato-SemiboldItalic.ttf",
+                 "Lato-MediumItalic.ttf": "Lato-HeavyItalic.ttf", "STIXGeneralItalic.ttf": "STIXGeneralBolIta.ttf",
+                 "DejaVuSans-Oblique.ttf": "DejaVuSans-BoldOblique.ttf",
+                 "DejaVuSerif-Italic.ttf": "DejaVuSerif-BoldItalic.ttf"}.get(fname, fname)
     fb = named_font(bold_name if font_path(bold_name) else fname, int(px * 1.3))
     line_h = int(px * rng.uniform(1.45, 1.7))
     ink = lambda: int(rng.integers(5, 80))

@@ -217,6 +217,28 @@ def drop_running_lines(content: List[dict], n_pages: int) -> Tuple[List[dict], L
     return kept, dropped
 
 
+_FIG_CAPTION = re.compile(r"^(figure|fig\.?|abbildung|abb\.?|figura|рисунок|рис\.?|εικόνα|chart|image)\s*\d+", re.I)
+_TAB_CAPTION = re.compile(r"^(table|tabelle|tab\.?|tabla|tableau|таблица|табл\.?|πίνακας)\s*\d+", re.I)
+
+
+def attach_captions(items: List[dict]) -> None:
+    """The paragraph next to a figure / table that starts like a caption ("Figure 3:", "Abb. 2", "Table 1.") is
+    recorded on that item as ``img_caption`` / ``table_caption`` (magic-pdf's content-list fields).  Unlike there, the
+    paragraph also stays in the list as text: the reference's combined text takes only items with a 'text' key
+    (services/ocr_service/ocr_service.py:229-243), and a caption is worth keeping in it."""
+    for k, it in enumerate(items):
+        if it["type"] == "image":
+            pat, key, near = _FIG_CAPTION, "img_caption", (k + 1, k - 1)       # usually below the figure
+        elif it["type"] == "table":
+            pat, key, near = _TAB_CAPTION, "table_caption", (k - 1, k + 1)     # usually above the table
+        else:
+            continue
+        for j in near:
+            if 0 <= j < len(items) and items[j]["type"] == "text" and pat.match(items[j]["text"]):
+                it[key] = [items[j]["text"]]
+                break
+
+
 def page_content_items(pg: PageResult) -> List[dict]:
     """Content-list items of one page.  Image items carry ``'figure'``: the position of their crop in
     ``pg.figures`` (dropped by ``build_content_list``; the packed wire form keeps it, runtime/wire.py)."""
@@ -229,9 +251,10 @@ def page_content_items(pg: PageResult) -> List[dict]:
         items += _line_items(pg.lines[li : li + take], pg.page_index, float(pg.height))
         li += take
         pos += take + 1
-        items.append({"type": "image", "img_path": fg.path, "page_idx": pg.page_index,
+        items.append({"type": "image", "img_path": fg.path, "img_caption": [], "img_footnote": [], "page_idx": pg.page_index,
                       "bbox": [round(float(v), 1) for v in fg.box], "figure": k})
     items += _line_items(pg.lines[li:], pg.page_index, float(pg.height))
+    attach_captions(items)
     return items
 
 

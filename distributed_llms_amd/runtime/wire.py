@@ -83,14 +83,15 @@ def pack_shard(pages: Sequence[Tuple[int, Optional[object]]], items_of=None) -> 
                 if t == "table":
                     # cells never hold a tab or a line break: rows on lines, cells between tabs
                     i_kind.append(ITEM_TABLE)
-                    i_texts.append("\n".join("\t".join(c.replace("\t", " ").replace("\n", " ") for c in row)
+                    i_texts.append("".join(it.get("table_caption") or []) + "\f" +
+                                   "\n".join("\t".join(c.replace("\t", " ").replace("\n", " ") for c in row)
                                              for row in it["cells"]))
                 elif t == "text" and it.get("margin"):
                     i_kind.append(ITEM_MARGIN_TOP if it["margin"] == "top" else ITEM_MARGIN_BOTTOM)
                     i_texts.append(it["text"])
                 else:
                     i_kind.append(ITEM_IMAGE if t == "image" else (ITEM_EQUATION if t == "equation" else ITEM_TEXT))
-                    i_texts.append(it.get("text", ""))
+                    i_texts.append("".join(it.get("img_caption") or []) if t == "image" else it.get("text", ""))
                 i_box.append(tuple(it.get("bbox") or (0.0, 0.0, 0.0, 0.0)))
                 i_fig.append(base + int(it.get("figure", 0)) if t == "image" else -1)
         line_off[k + 1] = len(texts)
@@ -211,15 +212,20 @@ class PackedShard:
             kd = int(self.i_kind[j])
             if kd == ITEM_IMAGE:
                 f = int(self.i_fig[j])
-                out.append({"type": "image", "img_path": (fig_paths or {}).get(f, ""), "page_idx": pi,
-                            "bbox": [round(float(v), 1) for v in self.i_box[j]]})
+                cap = t[off[j] : off[j + 1]]
+                out.append({"type": "image", "img_path": (fig_paths or {}).get(f, ""), "img_caption": [cap] if cap else [],
+                            "img_footnote": [], "page_idx": pi, "bbox": [round(float(v), 1) for v in self.i_box[j]]})
             elif kd == ITEM_EQUATION:
                 out.append({"type": "equation", "text": t[off[j] : off[j + 1]], "text_format": "latex", "page_idx": pi,
                             "bbox": [round(float(v), 1) for v in self.i_box[j]]})
             elif kd == ITEM_TABLE:
                 from .document import table_item
 
-                out.append(table_item([r.split("\t") for r in t[off[j] : off[j + 1]].split("\n")], pi, self.i_box[j]))
+                cap, _, body = t[off[j] : off[j + 1]].partition("\f")
+                tab = table_item([r.split("\t") for r in body.split("\n")], pi, self.i_box[j])
+                if cap:
+                    tab["table_caption"] = [cap]
+                out.append(tab)
             elif kd in (ITEM_MARGIN_TOP, ITEM_MARGIN_BOTTOM):
                 out.append({"type": "text", "text": t[off[j] : off[j + 1]], "page_idx": pi,
                             "margin": "top" if kd == ITEM_MARGIN_TOP else "bottom"})

@@ -70,7 +70,7 @@ def render_training_page(seed: int, fonts=None, plain_share: float = 0.2, max_sk
     skew = float(rng.uniform(-max_skew, max_skew)) if rng.random() < 0.7 else 0.0
     blur = float(rng.uniform(0.3, 1.1)) if rng.random() < 0.4 else 0.0
     if script_share > 0 and np.random.default_rng(seed ^ 0x5C21).random() < script_share:
-        pg, truth = synth.render_layout_page(seed, fonts=fonts or synth.TRAIN_FONTS, skew=skew, blur=blur,
+        pg, truth = synth.render_layout_page(seed, fonts=fonts or synth.SCRIPT_TRAIN_FONTS, skew=skew, blur=blur,
                                              noise=float(rng.uniform(0.5, 5.0)), script="cyrillic" if seed % 2 else "greek")
         return augment_scan(pg, rng), truth
     pg, truth = synth.render_layout_page(seed, fonts=fonts or synth.TRAIN_FONTS, skew=skew, blur=blur,
@@ -403,8 +403,9 @@ def evaluate(det, rec, device, seeds, verbose=False, formula_weights=None):
     if rec.multi_script:
         for name, sc in (("russian_held_out_fonts", "cyrillic"), ("greek_held_out_fonts", "greek")):
             out[name] = evaluate_pages(
-                eng, [synth.render_layout_page(sd, fonts=lato, script=sc, layout=synth.LAYOUTS[k % len(synth.LAYOUTS)],
-                                               skew=2.0 * (1 if k % 2 == 0 else -1)) for k, sd in enumerate(seeds[:6])], verbose)
+                eng, [synth.render_layout_page(sd, fonts=synth.SCRIPT_HELD_OUT_FONTS, script=sc,
+                                               layout=synth.LAYOUTS[k % len(synth.LAYOUTS)],
+                                               skew=2.0 * (1 if k % 2 == 0 else -1)) for k, sd in enumerate(seeds)], verbose)
     out["formula_pages"] = evaluate_pages(eng, [synth.render_layout_page(sd, fonts=synth.TRAIN_FONTS, formulas=0.8,
                                                                          layout=synth.LAYOUTS[k % 3])
                                                 for k, sd in enumerate(seeds[:4])], verbose)
@@ -422,7 +423,9 @@ def write_meta(out_dir: str, steps: int, ev, log, charset: str = "", history: st
                                 "contrast": [0.7, 1.15], "jpeg_quality": [35, 95], "font_px": [30, 50],
                                 "layouts": list(synth.LAYOUTS) + ["plain"],
                                 "display_formulas": "40 % of the layout pages carry formulas (synth.random_formula, mathtext)",
-                                "western_european_pages": "35 % of the layout pages (synth._WORDS_I18N)"}},
+                                "western_european_pages": "35 % of the layout pages (synth._WORDS_I18N)",
+                                "script_train_fonts": synth.available_fonts(synth.SCRIPT_TRAIN_FONTS),
+                                "script_held_out_fonts": synth.available_fonts(synth.SCRIPT_HELD_OUT_FONTS)}},
               open(os.path.join(out_dir, "train_meta.json"), "w"), indent=1)
 
 

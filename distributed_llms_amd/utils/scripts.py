@@ -29,10 +29,12 @@ _GRK_TO_LATIN = dict(zip("ΑΒΕΖΗΙΚΜΝΟΡΤΥΧοό", "ABEZHIKMNOPTYXoó"
 HOMOGLYPHS: Dict[str, str] = {**_CYR_TO_LATIN, **_GRK_TO_LATIN}
 _LATIN_TO_CYR = {v: k for k, v in _CYR_TO_LATIN.items()}
 _LATIN_TO_GRK = {v: k for k, v in _GRK_TO_LATIN.items()}
-# near-shapes the recogniser may pick inside a word of the other alphabet; applied only to words already known to be
-# Cyrillic / Greek from their unambiguous letters
-_LATIN_TO_CYR_SOFT = {**_LATIN_TO_CYR, "k": "к"}
-_LATIN_TO_GRK_SOFT = {**_LATIN_TO_GRK, "v": "ν", "u": "υ", "k": "κ", "i": "ι"}
+# Near-shapes the recogniser may pick inside a word of the other alphabet, applied only to words already known to be
+# Cyrillic / Greek from their unambiguous letters.  In italic cuts several of them are the very same glyph: Cyrillic
+# и, п, т, г, д are drawn as u, n, m, r-like and g-like forms, Greek alpha as a, nu as v.
+_LATIN_TO_CYR_SOFT = {**_LATIN_TO_CYR, "k": "к", "u": "и", "n": "п", "m": "т", "r": "г", "g": "д"}
+_LATIN_TO_GRK_SOFT = {**_LATIN_TO_GRK, "v": "ν", "u": "υ", "k": "κ", "i": "ι", "a": "α", "n": "η", "p": "ρ", "w": "ω",
+                      "t": "τ", "e": "ε", "x": "χ", "y": "γ", "á": "ά", "í": "ί", "é": "έ"}
 
 _CYR_ONLY = frozenset(CYRILLIC_EXTRA) - {"№"}
 _GRK_ONLY = frozenset(GREEK_EXTRA)
@@ -40,8 +42,6 @@ _SHARED = frozenset(HOMOGLYPHS.values())
 _VISUAL = str.maketrans(HOMOGLYPHS)
 _TO_CYR = str.maketrans(_LATIN_TO_CYR_SOFT)
 _TO_GRK = str.maketrans(_LATIN_TO_GRK_SOFT)
-_TO_CYR_HARD = str.maketrans(_LATIN_TO_CYR)
-_TO_GRK_HARD = str.maketrans(_LATIN_TO_GRK)
 
 
 def to_visual(text: str) -> str:
@@ -56,7 +56,7 @@ def _counts(word: str):
             cyr += 1
         elif c in _GRK_ONLY:
             grk += 1
-        elif c.isalpha() and c not in _SHARED:
+        elif c.isalpha() and c not in _SHARED and c not in HOMOGLYPHS:
             lat += 1
     return cyr, grk, lat
 
@@ -71,6 +71,15 @@ def line_script(text: str) -> str:
     if grk > max(cyr, lat):
         return "greek"
     return "latin"
+
+
+def _short_foreign(word: str, dom: str) -> bool:
+    """A word of at most three letters, in a line of the other alphabet, all of whose letters have a (near-)twin
+    there: the italic "no", "om", "u" of a Russian line are по, от, и.  Longer words stay as read - an English word
+    inside a Russian sentence is far more likely than five twins in a row."""
+    table = _LATIN_TO_CYR_SOFT if dom == "cyrillic" else _LATIN_TO_GRK_SOFT
+    letters = [c for c in word if c.isalpha()]
+    return 0 < len(letters) <= 3 and all(c in table for c in letters)
 
 
 def resolve_scripts(text: str, hint: Optional[str] = None) -> str:
@@ -90,10 +99,8 @@ def resolve_scripts(text: str, hint: Optional[str] = None) -> str:
             word = word.translate(_TO_CYR)
         elif grk and grk >= max(cyr, lat):
             word = word.translate(_TO_GRK)
-        elif lat == 0 and dom == "cyrillic":
-            word = word.translate(_TO_CYR_HARD)
-        elif lat == 0 and dom == "greek":
-            word = word.translate(_TO_GRK_HARD)
+        elif dom != "latin" and not (cyr or grk) and (lat == 0 or _short_foreign(word, dom)):
+            word = word.translate(_TO_CYR if dom == "cyrillic" else _TO_GRK)
         out.append(word)
     return " ".join(out)
 

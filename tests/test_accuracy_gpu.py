@@ -238,3 +238,17 @@ def test_russian_and_greek_pages_in_held_out_fonts(pipe, script, probe):
     assert ev["cer"] < 0.04, ev
     doc = pipe.process_pdf(synth.make_scanned_pdf([pages[0][0]], codec="jpeg"), script)
     assert doc.language == script, (doc.language, doc.language_confidence)
+
+
+def test_bilevel_fax_quality_scan_is_read(pipe):
+    """A 1-bit scan (CCITT Group 4, what fax machines and archive scanners write): thresholded ink, no grey levels,
+    jagged edges - read through the same detector and recogniser."""
+    pg, tr = synth.render_layout_page(303_030, layout="two_col", fonts=["DejaVuSerif.ttf"], noise=0.0, header_footer=False)
+    doc = pipe.process_pdf(synth.make_scanned_pdf([pg], codec="ccitt"), "fax")
+    assert doc.mode == "ocr" and not doc.warnings
+    got = [l.text.strip() for l in doc.pages[0].lines]
+    want = [t.strip() for t in tr.texts]
+    assert abs(len(got) - len(want)) <= 1, (len(got), len(want))
+    cer = _cer(" ".join(" ".join(got).split()), " ".join(" ".join(want).split()))
+    print("bilevel scan CER:", cer)
+    assert cer < 0.03, cer

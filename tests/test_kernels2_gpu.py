@@ -283,11 +283,11 @@ def test_row_argmax_small_vocab_confidence_is_finite(V):
         assert torch.equal(ids[n, : int(rln[n])].cpu(), rids[n, : int(rln[n])])
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 5])
 @pytest.mark.parametrize("N", [40, 300])
 def test_lstm_ragged_variants_match_reference(N, variant):
-    """Every recurrence kernel (v1, v2 with 16 / 32 sequences per workgroup, v3 with half of W_hh resident in
-    registers + LDS) and the automatic choice, on a ragged, length-sorted layout."""
+    """Every recurrence kernel (the generic 4-wave one, v4 with 6 / 8 and with 7 / 8 of W_hh resident in registers +
+    LDS) and the automatic choice, on a ragged, length-sorted layout."""
     from distributed_llms_amd.ops import lstm
 
     lstm.set_kernel_variant(variant)
