@@ -228,6 +228,17 @@ def main():
     import torch.distributed as dist
 
     use_gpu = torch.cuda.is_available() and not args.cpu
+    pinned_to = None
+    if use_gpu and world > 1 and os.environ.get("DLAMD_BENCH_NO_PIN") != "1":
+        # One rank per GPU on a shared host: keep this rank's threads (decode pool, pinned-buffer allocations, the
+        # engine's host thread) on the cores next to its GPU, or on its slice of the allowed cores, so that eight ranks
+        # do not migrate over both sockets.  Needs at least two cores per rank to be worth it.
+        from distributed_llms_amd.utils.affinity import allowed_cpus, cpus_for_worker, pin_process
+
+        if len(allowed_cpus()) >= 2 * world:
+            mine = cpus_for_worker(local_rank, world)
+            if pin_process(mine):
+                pinned_to = len(mine)
     if use_gpu:
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
@@ -410,6 +421,7 @@ def main():
                 "documents": "queued back to back through one engine pipeline" if stream_docs else "one at a time",
                 "lines_recognized": n_lines,
                 "host_cpu_s_per_100_pages": round(100.0 * host_cpu / (args.steps * args.pages_per_doc), 4),
+                "cores_pinned_per_rank": pinned_to,
                 "weights": "trained (weights/)" if trained else "random-init",
                 "cer_vs_truth": None if cer is None else round(cer, 5),
                 "baseline": "CPU proxy: same graphs, torch CPU eager, ProcessPoolExecutor(8) on 8 vCPU = 0.84 pages/s "
