@@ -101,8 +101,13 @@ struct Bits {
   bool eof() const { return pos >= n * 8; }
   // next k bits (k <= 24) without consuming, zero padded past the end
   uint32_t peek(int k) const {
+    const size_t byte = pos >> 3;
+    if (byte + 8 <= n) {                 // one unaligned 8-byte load, big-endian: the next bit is the top bit
+      uint64_t w;
+      memcpy(&w, p + byte, 8);
+      return (uint32_t)((__builtin_bswap64(w) << (pos & 7)) >> (64 - k));
+    }
     uint32_t v = 0;
-    size_t byte = pos >> 3;
     for (int i = 0; i < 4; ++i) v = (v << 8) | (byte + i < n ? p[byte + i] : 0u);
     return (v << (pos & 7)) >> (32 - k);
   }

@@ -429,6 +429,24 @@ long long dlpdf_image_decode(void* hp, int page, int idx, uint8_t* dst, size_t d
         // short, long or damaged streams: the general path below pads / truncates / tolerates as before
       }
     }
+    // the same layout written by image tools: rows PNG-predicted before deflating.  Inflate into a scratch buffer, undo
+    // the row filters straight into the caller's buffer.
+    if (im.filters.size() == 1 && (im.filters[0] == "FlateDecode" || im.filters[0] == "Fl") && im.parms[0][0] >= 10 &&
+        im.bpc == 8 && !im.indexed && !im.invert && !im.mask && (im.ncomp == 1 || im.ncomp == 3) &&
+        im.parms[0][1] == im.ncomp && im.parms[0][2] == 8 && im.parms[0][3] == im.width) {
+      const size_t rowbytes = (size_t)im.width * im.ncomp, need = rowbytes * im.height;
+      if (dst_len >= need) {
+        const uint8_t* p = im.owned ? (const uint8_t*)im.owned->data() : h->doc->data() + im.off;
+        const size_t len = im.owned ? im.owned->size() : im.len;
+        static thread_local std::vector<uint8_t> scratch;
+        const size_t packed = (rowbytes + 1) * im.height;
+        if (scratch.size() < packed) scratch.resize(packed);
+        if (fastinflate::inflate_zlib(p, len, scratch.data(), packed) == (long long)packed) {
+          png_unpredict_rows(scratch.data(), im.height, rowbytes, im.ncomp, dst);
+          return (long long)need;
+        }
+      }
+    }
     std::string raw = run_filters(h->doc->data(), im);
     const int W = im.width, H = im.height, nc = im.ncomp, bpc = im.bpc;
     const bool color = (!im.indexed && (nc == 3 || nc == 4)) || (im.indexed && im.palette_comps >= 3);
@@ -440,6 +458,25 @@ long long dlpdf_image_decode(void* hp, int page, int idx, uint8_t* dst, size_t d
     // fast path: 8-bit gray / RGB, no palette
     if (bpc == 8 && !im.indexed && !im.invert && (nc == 1 || nc == 3)) {
       memcpy(dst, raw.data(), need);
+      return (long long)need;
+    }
+    // bilevel pages (CCITT fax, 1-bit Flate): a table turns every input byte into its eight output pixels at once
+    // (the general loop below spends ~6 ns per pixel, 50 ms for an A4 page at 300 DPI)
+    if (bpc == 1 && nc == 1 && !im.indexed) {
+      uint64_t lut[256];
+      const uint8_t on = im.invert ? 0 : 255, off = im.invert ? 255 : 0;
+      for (int v = 0; v < 256; ++v) {
+        uint8_t px[8];
+        for (int k = 0; k < 8; ++k) px[k] = (v >> (7 - k)) & 1 ? on : off;
+        memcpy(&lut[v], px, 8);
+      }
+      const int whole = W >> 3;
+      for (int y = 0; y < H; ++y) {
+        const uint8_t* row = (const uint8_t*)raw.data() + (size_t)y * rowbytes;
+        uint8_t* o = dst + (size_t)y * W;
+        for (int b = 0; b < whole; ++b) memcpy(o + 8 * b, &lut[row[b]], 8);
+        for (int x = whole << 3; x < W; ++x) o[x] = (row[x >> 3] >> (7 - (x & 7))) & 1 ? on : off;
+      }
       return (long long)need;
     }
     const int maxv = (1 << std::min(bpc, 8)) - 1;

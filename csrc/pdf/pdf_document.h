@@ -160,6 +160,79 @@ inline std::string lzw_decode(const uint8_t* s, size_t n, int early = 1) {
 }
 
 // PNG / TIFF predictors (DecodeParms of Flate / LZW).
+// PNG row filters undone straight into the destination raster (no intermediate copy): ``data`` holds ``rows`` rows of
+// 1 filter byte + ``rowbytes`` bytes; ``dst`` receives rows * rowbytes bytes.  Up rows vectorise; Sub / Average / Paeth
+// carry a dependency from pixel to pixel, so their loops are kept free of branches and of the "is there a left
+// neighbour" test (the first bpp bytes are handled apart).
+inline void png_unpredict_rows(const uint8_t* data, size_t rows, size_t rowbytes, int bpp, uint8_t* dst) {
+  const size_t stride = rowbytes + 1;
+  std::vector<uint8_t> zero(rowbytes, 0);
+  const size_t B = (size_t)bpp;
+  for (size_t y = 0; y < rows; ++y) {
+    const uint8_t ft = data[y * stride];
+    const uint8_t* in = data + y * stride + 1;
+    uint8_t* cur = dst + y * rowbytes;
+    const uint8_t* up = y ? cur - rowbytes : zero.data();
+    const size_t head = B < rowbytes ? B : rowbytes;
+    switch (ft) {
+      case 1:
+        for (size_t i = 0; i < head; ++i) cur[i] = in[i];
+        if (B == 1) {
+          unsigned a = cur[0];
+          for (size_t i = 1; i < rowbytes; ++i) {
+            a = (a + in[i]) & 255u;
+            cur[i] = (uint8_t)a;
+          }
+        } else {
+          for (size_t i = head; i < rowbytes; ++i) cur[i] = (uint8_t)(in[i] + cur[i - B]);
+        }
+        break;
+      case 2:
+        for (size_t i = 0; i < rowbytes; ++i) cur[i] = (uint8_t)(in[i] + up[i]);
+        break;
+      case 3:
+        for (size_t i = 0; i < head; ++i) cur[i] = (uint8_t)(in[i] + (up[i] >> 1));
+        if (B == 1) {
+          // the left neighbour stays in a register: reading back the byte just stored costs a store-to-load forward
+          // per pixel, which is most of this loop's time
+          unsigned a = cur[0];
+          for (size_t i = 1; i < rowbytes; ++i) {
+            a = (in[i] + ((a + up[i]) >> 1)) & 255u;
+            cur[i] = (uint8_t)a;
+          }
+        } else {
+          for (size_t i = head; i < rowbytes; ++i) cur[i] = (uint8_t)(in[i] + ((cur[i - B] + up[i]) >> 1));
+        }
+        break;
+      case 4:
+        for (size_t i = 0; i < head; ++i) cur[i] = (uint8_t)(in[i] + up[i]);        // a = c = 0: the predictor is b
+        if (B == 1) {
+          int a = cur[0], c = up[0];
+          for (size_t i = 1; i < rowbytes; ++i) {
+            const int b = up[i];
+            const int da = b - c, db = a - c;            // p - a, p - b; p - c is their sum
+            const int pa = da < 0 ? -da : da, pb = db < 0 ? -db : db, pc = da + db < 0 ? -(da + db) : da + db;
+            const int ab = pa <= pb ? a : b, pab = pa <= pb ? pa : pb;
+            a = (in[i] + (pab <= pc ? ab : c)) & 255;
+            cur[i] = (uint8_t)a;
+            c = b;
+          }
+        } else {
+          for (size_t i = head; i < rowbytes; ++i) {
+            const int a = cur[i - B], b = up[i], c = up[i - B];
+            const int da = b - c, db = a - c;
+            const int pa = da < 0 ? -da : da, pb = db < 0 ? -db : db, pc = da + db < 0 ? -(da + db) : da + db;
+            const int ab = pa <= pb ? a : b, pab = pa <= pb ? pa : pb;
+            cur[i] = (uint8_t)(in[i] + (pab <= pc ? ab : c));
+          }
+        }
+        break;
+      default:
+        memcpy(cur, in, rowbytes);
+    }
+  }
+}
+
 inline std::string apply_predictor(std::string data, int predictor, int colors, int bpc, int columns) {
   if (predictor <= 1) return data;
   const int bpp = std::max(1, colors * bpc / 8);
@@ -174,41 +247,10 @@ inline std::string apply_predictor(std::string data, int predictor, int colors, 
     return data;
   }
   // PNG predictors: each row is prefixed by a filter-type byte
-  const size_t stride = rowbytes + 1;
-  const size_t rows = data.size() / stride;
-  std::string out(rows * rowbytes, '\0');
-  std::vector<uint8_t> zero(rowbytes, 0);
-  for (size_t y = 0; y < rows; ++y) {
-    const uint8_t* in = (const uint8_t*)&data[y * stride];
-    uint8_t ft = in[0];
-    ++in;
-    uint8_t* cur = (uint8_t*)&out[y * rowbytes];
-    const uint8_t* up = y ? (const uint8_t*)&out[(y - 1) * rowbytes] : zero.data();
-    switch (ft) {
-      case 0: memcpy(cur, in, rowbytes); break;
-      case 1:
-        for (size_t i = 0; i < rowbytes; ++i) cur[i] = (uint8_t)(in[i] + (i >= (size_t)bpp ? cur[i - bpp] : 0));
-        break;
-      case 2:
-        for (size_t i = 0; i < rowbytes; ++i) cur[i] = (uint8_t)(in[i] + up[i]);
-        break;
-      case 3:
-        for (size_t i = 0; i < rowbytes; ++i) {
-          int a = i >= (size_t)bpp ? cur[i - bpp] : 0;
-          cur[i] = (uint8_t)(in[i] + ((a + up[i]) >> 1));
-        }
-        break;
-      case 4:
-        for (size_t i = 0; i < rowbytes; ++i) {
-          int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = up[i], c = i >= (size_t)bpp ? up[i - bpp] : 0;
-          int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
-          int pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-          cur[i] = (uint8_t)(in[i] + pr);
-        }
-        break;
-      default: memcpy(cur, in, rowbytes);
-    }
-  }
+  const size_t rows = data.size() / (rowbytes + 1);
+  std::string out;
+  out.resize(rows * rowbytes);
+  png_unpredict_rows((const uint8_t*)data.data(), rows, rowbytes, bpp, (uint8_t*)&out[0]);
   return out;
 }
 
