@@ -90,8 +90,8 @@ struct Cutter {
   }
 
   // A region is a table when its boxes form a grid: at least ``min_rows`` rows of two or more cells each, the cells
-  // of all rows falling into common columns (the whitespace between the columns runs through every row, at least a
-  // line height wide), no row with two cells in one column, every column filled in at least half of the rows, and at
+  // of all rows falling into common columns (the whitespace between the columns runs through every row, at least 0.6
+  // line heights wide), no row with two cells in one column, every column filled in at least half of the rows, and at
   // most one column of long text (two columns of running text whose lines happen to share baselines are not a table).
   bool is_table(const std::vector<int>& idx, int min_rows) const {
     if ((int)idx.size() < 2 * min_rows) return false;
@@ -100,7 +100,7 @@ struct Cutter {
     if ((int)rows.size() < min_rows) return false;
     for (auto& r : rows) if (r.size() < 2) return false;
     std::vector<double> cuts;
-    for (auto& g : gaps<false>(idx)) if (g.width >= h_med) cuts.push_back(0.5 * (g.start + g.end));
+    for (auto& g : gaps<false>(idx)) if (g.width >= 0.6 * h_med) cuts.push_back(0.5 * (g.start + g.end));
     if (cuts.empty()) return false;
     std::sort(cuts.begin(), cuts.end());
     const size_t C = cuts.size() + 1;
@@ -140,11 +140,19 @@ struct Cutter {
     ++n_blocks;
   }
 
+  // A side of a vertical cut counts as a column of running text when it holds several lines that are much wider than
+  // tall: the median aspect reaches text_aspect, or - a column that also holds a table, whose many short cells pull
+  // the median down - at least a quarter of its boxes (and min_col_lines of them) are long lines (aspect >= 8).
   bool is_text_column(const std::vector<int>& idx) const {
     if ((int)idx.size() < min_col_lines) return false;
     std::vector<double> r;
-    for (int i : idx) r.push_back((b[i].x1 - b[i].x0) / std::max(b[i].y1 - b[i].y0, 1.0));
-    return median(r) >= text_aspect;
+    int longs = 0;
+    for (int i : idx) {
+      r.push_back((b[i].x1 - b[i].x0) / std::max(b[i].y1 - b[i].y0, 1.0));
+      longs += r.back() >= 8.0;
+    }
+    if (median(r) >= text_aspect) return true;
+    return longs >= min_col_lines && 4 * longs >= (int)idx.size();
   }
 
   std::vector<double> column_cuts(const std::vector<int>& idx) const {

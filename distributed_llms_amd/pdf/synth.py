@@ -526,8 +526,8 @@ def render_layout_page(seed: int, size: Tuple[int, int] = A4_300DPI, layout: Opt
 
 
 def render_table_page(seed: int, size: Tuple[int, int] = A4_300DPI, rows: int = 5, cols: int = 3, ruled: bool = True,
-                      row_pitch: float = 1.6, column: bool = False, font_name: str = "DejaVuSans.ttf"
-                      ) -> Tuple[np.ndarray, PageTruth, List[List[str]]]:
+                      row_pitch: float = 1.6, column: bool = False, font_name: str = "DejaVuSans.ttf",
+                      font_px: int = 38) -> Tuple[np.ndarray, PageTruth, List[List[str]]]:
     """A page with two paragraphs and a ``rows`` x ``cols`` table between them (first column labels, the others
     numbers or short words; optional ruling lines; ``row_pitch`` line heights from row to row).  ``column``: the page
     has two text columns and the table sits inside the left one.  The truth lists the lines in reading order with the
@@ -535,7 +535,7 @@ def render_table_page(seed: int, size: Tuple[int, int] = A4_300DPI, rows: int = 
     W, H = size
     rng = np.random.default_rng(seed)
     scale = W / 2480.0
-    px = max(8, int(38 * scale))
+    px = max(8, int(font_px * scale))
     margin = max(6, int(200 * scale))
     img = Image.new("L", (W, H), 244)
     d = ImageDraw.Draw(img)

@@ -463,6 +463,13 @@ class OcrEngine:
                 inside = ((cx[:, None] >= fg[None, :, 0]) & (cx[:, None] <= fg[None, :, 2]) &
                           (cy[:, None] >= fg[None, :, 1]) & (cy[:, None] <= fg[None, :, 3]))
                 real = inside.sum(0) < cfg.fig_max_lines
+                for k in np.nonzero(real & (inside.sum(0) >= 2))[0]:
+                    # a ruled table looks like a framed figure to the block head (often only part of it): when the
+                    # text lines on the rows that cross the "figure" form a grid of cells, it is a table - its lines
+                    # stay text and the layout analysis makes them a table block
+                    rows = (cy >= fg[k, 1]) & (cy <= fg[k, 3])
+                    if int(rows.sum()) >= 6 and layout.boxes_form_table(r[rows, :4]):
+                        real[k] = False
                 fg, inside = fg[real], inside[:, real]
                 r = r[~inside.any(1)]
             if r.shape[0] == 0 and fg.shape[0] == 0:

@@ -96,7 +96,7 @@ class _Cutter:
     def is_table(self, idx: np.ndarray, min_rows: int) -> bool:
         """A region is a table when its boxes form a grid: at least ``min_rows`` rows of two or more cells each, the
         cells of all rows falling into common columns (the whitespace between the columns runs through every row, at
-        least a line height wide), no row with two cells in one column, every column filled in at least half of the
+        least 0.6 line heights wide), no row with two cells in one column, every column filled in at least half of the
         rows, and at most one column of long text (two columns of running text whose lines happen to share baselines
         are not a table).  Cells that wrap onto a second line are not handled: such a region stays ordinary text."""
         b = self.b
@@ -107,7 +107,7 @@ class _Cutter:
         rows = self.rows_of(idx)
         if len(rows) < min_rows or any(r.size < 2 for r in rows):
             return False
-        cuts = sorted(0.5 * (s + e) for w, s, e in _gaps(b[idx, 0], b[idx, 2]) if w >= self.h_med)
+        cuts = sorted(0.5 * (s + e) for w, s, e in _gaps(b[idx, 0], b[idx, 2]) if w >= 0.6 * self.h_med)
         if not cuts:
             return False
         C = len(cuts) + 1
@@ -132,7 +132,11 @@ class _Cutter:
             return False
         w = self.b[idx, 2] - self.b[idx, 0]
         h = np.maximum(self.b[idx, 3] - self.b[idx, 1], 1.0)
-        return float(np.median(w / h)) >= self.text_aspect
+        if float(np.median(w / h)) >= self.text_aspect:
+            return True
+        # a column that also holds a table: the many short cells pull the median down, the long lines are still there
+        longs = int(np.count_nonzero(w / h >= 8.0))
+        return longs >= self.min_col_lines and 4 * longs >= idx.size
 
     def column_cuts(self, idx: np.ndarray) -> List[float]:
         g = [x for x in _gaps(self.b[idx, 0], self.b[idx, 2]) if x[0] >= self.tx]
@@ -216,6 +220,14 @@ def reading_order(boxes: np.ndarray, col_gap: float = 1.2, block_gap: float = 0.
     if with_tables:
         return np.asarray(c.order, dtype=np.int64), c.block_of, np.asarray(c.table_block, bool)[c.block_of]
     return np.asarray(c.order, dtype=np.int64), c.block_of
+
+
+def boxes_form_table(boxes: np.ndarray, min_rows: int = 3) -> bool:
+    """Do these boxes, taken together, form one table (``_Cutter.is_table``)?"""
+    boxes = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)
+    if boxes.shape[0] < 2 * min_rows:
+        return False
+    return _Cutter(boxes, 1.2, 0.9, 3, 4.0).is_table(np.arange(boxes.shape[0]), min_rows)
 
 
 def split_margins(boxes: np.ndarray, page_h: float, band: float = 0.075) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:

@@ -59,7 +59,7 @@ def augment_scan(pg: np.ndarray, rng: np.random.Generator) -> np.ndarray:
 
 
 def render_training_page(seed: int, fonts=None, plain_share: float = 0.2, max_skew: float = 5.0, formula_share: float = 0.4,
-                         i18n_share: float = 0.35, script_share: float = 0.0):
+                         i18n_share: float = 0.35, script_share: float = 0.0, table_share: float = 0.0):
     """One page of the training distribution (see the module docstring) and its truth.  ``i18n_share`` of the layout
     pages are written in the Western European vocabulary (accented letters, sharp s, ligatures, currency signs);
     ``script_share`` of them in Russian or Greek (half each, ``utils.scripts``)."""
@@ -67,6 +67,15 @@ def render_training_page(seed: int, fonts=None, plain_share: float = 0.2, max_sk
     if rng.random() < plain_share:
         pg, truth = synth.render_page(seed, font_px=int(rng.integers(34, 50)), noise=float(rng.uniform(0.5, 4.0)))
         return pg, truth
+    if table_share > 0 and np.random.default_rng(seed ^ 0x7AB1).random() < table_share:
+        # ruled and unruled tables: text next to ruling lines, short cells, numbers
+        r2 = np.random.default_rng(seed ^ 0x7AB2)
+        names = [f for f in synth.available_fonts(fonts or synth.TRAIN_FONTS) if not f.startswith("cm")]
+        pg, truth, _ = synth.render_table_page(seed, rows=int(r2.integers(3, 14)), cols=int(r2.integers(2, 6)),
+                                               ruled=bool(r2.random() < 0.65), row_pitch=float(r2.uniform(1.3, 2.4)),
+                                               column=bool(r2.random() < 0.3), font_name=names[int(r2.integers(len(names)))],
+                                               font_px=int(r2.integers(28, 48)))
+        return augment_scan(pg, rng), truth
     skew = float(rng.uniform(-max_skew, max_skew)) if rng.random() < 0.7 else 0.0
     blur = float(rng.uniform(0.3, 1.1)) if rng.random() < 0.4 else 0.0
     if script_share > 0 and np.random.default_rng(seed ^ 0x5C21).random() < script_share:
@@ -84,10 +93,11 @@ class PageProducer:
     """Renders pages on host threads and keeps a bounded queue of (uint8 page tensor on device, truth)."""
 
     def __init__(self, device, threads: int = 6, depth: int = 24, seed0: int = 100_000, fonts=None,
-                 script_share: float = 0.0):
+                 script_share: float = 0.0, table_share: float = 0.0):
         self.device = device
         self.fonts = fonts
         self.script_share = script_share
+        self.table_share = table_share
         self.q: "queue.Queue" = queue.Queue(maxsize=depth)
         self._seed = seed0
         self._lock = threading.Lock()
@@ -101,7 +111,7 @@ class PageProducer:
             with self._lock:
                 self._seed += 1
                 seed = self._seed
-            pg, truth = render_training_page(seed, self.fonts, script_share=self.script_share)
+            pg, truth = render_training_page(seed, self.fonts, script_share=self.script_share, table_share=self.table_share)
             while not self._stop.is_set():
                 try:
                     self.q.put((torch.from_numpy(pg), truth), timeout=1.0)
@@ -443,6 +453,7 @@ def main(argv=None) -> int:
     ap.add_argument("--charset", choices=("latin", "multi"), default="latin",
                     help="multi: Latin + Cyrillic + Greek shape classes (utils/scripts.py)")
     ap.add_argument("--script-share", type=float, default=0.0, help="share of the layout pages written in Russian / Greek")
+    ap.add_argument("--table-share", type=float, default=0.0, help="share of the pages that carry a (ruled or unruled) table")
     ap.add_argument("--rec-only", action="store_true", help="leave the detector as it is: recogniser steps only")
     ap.add_argument("--lines", type=int, default=64, help="line crops per recogniser step")
     ap.add_argument("--history", default="", help="free text recorded in train_meta.json")
@@ -484,7 +495,7 @@ def main(argv=None) -> int:
     rec.own_conv_train = device.type == "cuda" and not args.library_convs
     dopt, ropt = _Opt(det, args.det_lr), _Opt(rec, args.rec_lr)
     it = start
-    prod = PageProducer(device, threads=args.threads, script_share=args.script_share)
+    prod = PageProducer(device, threads=args.threads, script_share=args.script_share, table_share=args.table_share)
     t0 = time.perf_counter()
     alive = threading.Event()
 

@@ -222,15 +222,21 @@ def test_running_header_and_page_numbers_are_left_out_of_a_scanned_document(pipe
 
 @pytest.mark.parametrize("script,probe", [("cyrillic", "жщыюя"), ("greek", "λπσωθ")])
 def test_russian_and_greek_pages_in_held_out_fonts(pipe, script, probe):
-    """Pages written in Russian / Greek (one word in ten English) in fonts the training never drew, turned by +-2
-    degrees, through detector boxes: the shape classes come back as the alphabet's own code points."""
+    """Pages written in Russian / Greek (one word in ten English) in ``synth.SCRIPT_HELD_OUT_FONTS`` - the STIX family,
+    never drawn in these alphabets, and three Lato cuts that are in no training set - turned by +-2 degrees, through
+    detector boxes: the shape classes come back as the alphabet's own code points."""
     from distributed_llms_amd.train.page_trainer import evaluate_pages
 
     if not getattr(pipe.engine.rec, "multi_script", False):
         pytest.skip("the shipped recogniser has no Cyrillic / Greek classes")
-    lato = [f for f in synth.HELD_OUT_FONTS if f.startswith("Lato")]
-    pages = [synth.render_layout_page(654_000 + k, fonts=lato, script=script, layout=synth.LAYOUTS[k % len(synth.LAYOUTS)],
-                                      skew=2.0 * (1 if k % 2 == 0 else -1)) for k in range(4)]
+    import json
+
+    meta = json.loads((WD / "train_meta.json").read_text())
+    assert set(meta["augmentation"]["script_held_out_fonts"]).isdisjoint(meta["augmentation"]["script_train_fonts"])
+    pages = [synth.render_layout_page(654_000 + k, fonts=synth.SCRIPT_HELD_OUT_FONTS, script=script,
+                                      layout=synth.LAYOUTS[k % len(synth.LAYOUTS)],
+                                      skew=2.0 * (1 if k % 2 == 0 else -1)) for k in range(6)]
+    assert {tr.font_names[0] for _, tr in pages} <= set(meta["augmentation"]["script_held_out_fonts"])
     assert sum(c in probe for _, tr in pages for t in tr.texts for c in t) > 50
     ev = evaluate_pages(pipe.engine, pages)
     print(script, "held-out fonts:", ev)

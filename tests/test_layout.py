@@ -180,6 +180,14 @@ def test_tables_are_found_and_read_row_by_row(kw):
         cells = [tr.texts[i] for i, k in zip(order, kind) if k == 2]
         assert cells == [c for row in grid for c in row]
         assert len({int(bk) for bk, k in zip(block, kind) if k == 2}) == 1
+        # boxes as a detector reports them: taller than the ink and a little wider
+        hm = float(np.median(tr.boxes[:, 3] - tr.boxes[:, 1]))
+        loose = tr.boxes + np.array([-0.05, -0.12, 0.05, 0.12], np.float32) * hm
+        a, b = layout.order_page(loose, arr.shape[0]), layout.order_page_native(loose, float(arr.shape[0]))
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+        assert b[0].tolist() == list(range(len(tr.texts)))
+        assert [tr.texts[i] for i, k in zip(b[0], b[2]) if k == 2] == [c for row in grid for c in row]
 
 
 def test_table_becomes_one_content_item_and_survives_the_wire():
