@@ -424,6 +424,9 @@ def main():
                 "cores_pinned_per_rank": pinned_to,
                 "weights": "trained (weights/)" if trained else "random-init",
                 "cer_vs_truth": None if cer is None else round(cer, 5),
+                "cer_scope": "pages of the generator the weights were trained on (seeds never drawn in training): shows "
+                             "that the timed output is the page text, not how the weights generalise "
+                             "(held-out fonts / scripts: weights/train_meta.json)",
                 "baseline": "CPU proxy: same graphs, torch CPU eager, ProcessPoolExecutor(8) on 8 vCPU = 0.84 pages/s "
                             "(bench/cpu_proxy.py; the reference publishes no number)",
             },

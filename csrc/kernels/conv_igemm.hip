@@ -913,6 +913,8 @@ extern "C" int dlamd_conv2d(const void* x, const void* w, const float* bias, con
     return sh == 1 ? dispatch_patch<1, 64, 2, 2>(a, stream) : dispatch_patch<2, 64, 2, 2>(a, stream);
   if (patch_ok && cfg == 3464)      // 256 pixels x 64 channels, 8 waves
     return sh == 1 ? dispatch_patch256<1, 64>(a, stream) : dispatch_patch256<2, 64>(a, stream);
+  // (A 512-pixel tile, 16 x 32 with 8 waves, halves the weight traffic once more but leaves one workgroup per CU: layer1
+  // 0.268 ms against 0.227, head 0.710 against 0.652 - measured and dropped.)
   if (patch_ok && cfg == 3428)      // 256 pixels x 128 channels, 8 waves
     return sh == 1 ? dispatch_patch256<1, 128>(a, stream) : dispatch_patch256<2, 128>(a, stream);
   // Auto mode, stride 1 (bench/conv64_probe.py, 25 detector pages): the 64-channel tile as 2 x 2 waves, where every

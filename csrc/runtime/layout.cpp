@@ -231,7 +231,80 @@ struct Cutter {
       }
       return;
     }
-    leaf(idx);
+    leaf_with_tables(idx);
+  }
+
+  // A region that no cut divides any further may still hold a table between its paragraphs (a table set close under a
+  // paragraph leaves no block gap): consecutive rows of two or more cells that form a grid become a table leaf, what
+  // lies above and below stays ordinary leaves, top to bottom.
+  // Last pass over the finished reading sequence: rows of a table that the cuts left in different leaves (the first
+  // row glued to the paragraph above it, the others a block gap apart) are consecutive in the sequence all the same.
+  // Consecutive rows of two or more cells, at most three line heights from one to the next, that form a grid become
+  // one table block of their own.
+  void tables_across_leaves() {
+    const size_t n = order.size();
+    auto cy = [&](int i) { return 0.5 * (b[i].y0 + b[i].y1); };
+    std::vector<std::pair<size_t, size_t>> rows;           // [first, last + 1) positions in order
+    size_t s = 0;
+    for (size_t k = 1; k <= n; ++k) {
+      if (k == n || std::fabs(cy(order[k]) - cy(order[s])) > 0.5 * h_med || b[order[k]].x0 <= b[order[k - 1]].x0) {
+        rows.push_back({s, k});
+        s = k;
+      }
+    }
+    size_t i = 0;
+    while (i < rows.size()) {
+      auto multi = [&](size_t r) { return rows[r].second - rows[r].first >= 2; };
+      if (!multi(i)) { ++i; continue; }
+      size_t j = i + 1;
+      while (j < rows.size() && multi(j) &&
+             b[order[rows[j].first]].y0 - b[order[rows[j - 1].first]].y1 <= 3.0 * h_med &&
+             cy(order[rows[j].first]) > cy(order[rows[j - 1].first]))
+        ++j;
+      bool all_table = true;
+      for (size_t k = rows[i].first; k < rows[j - 1].second; ++k) all_table &= table_block[block_of[order[k]]] != 0;
+      if (j - i >= 3 && !all_table) {
+        std::vector<int> cells(order.begin() + rows[i].first, order.begin() + rows[j - 1].second);
+        if (is_table(cells, 3)) {
+          table_block.push_back(1);
+          for (int c : cells) block_of[c] = n_blocks;
+          ++n_blocks;
+        }
+      }
+      i = j;
+    }
+  }
+
+  void leaf_with_tables(const std::vector<int>& idx) {
+    auto rows = rows_of(idx);
+    const size_t R = rows.size();
+    std::vector<std::pair<size_t, size_t>> tables;       // [first row, last row + 1)
+    size_t i = 0;
+    while (i < R) {
+      if (rows[i].size() < 2) { ++i; continue; }
+      size_t j = i;
+      while (j < R && rows[j].size() >= 2) ++j;
+      if (j - i >= 3) {
+        std::vector<int> cells;
+        for (size_t r = i; r < j; ++r) cells.insert(cells.end(), rows[r].begin(), rows[r].end());
+        if (is_table(cells, 3)) tables.push_back({i, j});
+      }
+      i = j;
+    }
+    if (tables.empty()) { leaf(idx); return; }
+    size_t at = 0;
+    auto emit = [&](size_t a, size_t b, bool table) {
+      if (a >= b) return;
+      std::vector<int> part;
+      for (size_t r = a; r < b; ++r) part.insert(part.end(), rows[r].begin(), rows[r].end());
+      leaf(part, table);
+    };
+    for (auto& t : tables) {
+      emit(at, t.first, false);
+      emit(t.first, t.second, true);
+      at = t.second;
+    }
+    emit(at, R, false);
   }
 };
 
@@ -245,6 +318,7 @@ void reading_order(const std::vector<Box>& boxes, std::vector<int>* order, std::
   std::vector<int> all(boxes.size());
   std::iota(all.begin(), all.end(), 0);
   c.cut(all, 0);
+  c.tables_across_leaves();
   *order = c.order;
   *block = c.block_of;
   if (in_table)

@@ -484,8 +484,9 @@ class OcrEngine:
             is_line = order < n
             lo = order[is_line]
             score = r[lo, 4:5] if r.shape[1] > 4 else np.ones((lo.size, 1), np.float32)
-            # kind: the detector's display-formula flag, else 2 for a cell of a table the layout analysis found
-            knd = np.where((kind[is_line] == 2) & (r[lo, 7] == 0), 2.0, r[lo, 7]).astype(np.float32)
+            # kind: 2 for a cell of a table the layout analysis found (a short cell that the formula channel took for a
+            # formula is a cell all the same: it sits in the grid), else the detector's display-formula flag
+            knd = np.where(kind[is_line] == 2, 2.0, r[lo, 7]).astype(np.float32)
             lines = np.concatenate([r[lo, :4], score, block[is_line][:, None].astype(np.float32), ang[lo][:, None],
                                     knd[:, None]], 1)
             pos = np.nonzero(~is_line)[0]

@@ -202,7 +202,68 @@ class _Cutter:
                 if s < len(ys):
                     self.leaf(wide[s : s + 1])
             return
-        self.leaf(idx)
+        self.leaf_with_tables(idx)
+
+    def tables_across_leaves(self) -> None:
+        """Last pass over the finished reading sequence: rows of a table that the cuts left in different leaves (the
+        first row glued to the paragraph above it, the others a block gap apart) are consecutive in the sequence all
+        the same.  Consecutive rows of two or more cells, at most three line heights from one to the next, that form a
+        grid become one table block of their own."""
+        b, order = self.b, self.order
+        n = len(order)
+        cy = lambda i: 0.5 * (b[i, 1] + b[i, 3])   # noqa: E731
+        rows, s = [], 0
+        for k in range(1, n + 1):
+            if k == n or abs(cy(order[k]) - cy(order[s])) > 0.5 * self.h_med or b[order[k], 0] <= b[order[k - 1], 0]:
+                rows.append((s, k))
+                s = k
+        i = 0
+        while i < len(rows):
+            if rows[i][1] - rows[i][0] < 2:
+                i += 1
+                continue
+            j = i + 1
+            while (j < len(rows) and rows[j][1] - rows[j][0] >= 2
+                   and b[order[rows[j][0]], 1] - b[order[rows[j - 1][0]], 3] <= 3.0 * self.h_med
+                   and cy(order[rows[j][0]]) > cy(order[rows[j - 1][0]])):
+                j += 1
+            cells = np.asarray(order[rows[i][0] : rows[j - 1][1]], dtype=np.int64)
+            all_table = all(self.table_block[self.block_of[c]] for c in cells)
+            if j - i >= 3 and not all_table and self.is_table(cells, 3):
+                self.table_block.append(True)
+                self.block_of[cells] = self.n_blocks
+                self.n_blocks += 1
+            i = j
+
+    def leaf_with_tables(self, idx: np.ndarray) -> None:
+        """A region that no cut divides any further may still hold a table between its paragraphs (a table set close
+        under a paragraph leaves no block gap): consecutive rows of two or more cells that form a grid become a table
+        leaf, what lies above and below stays ordinary leaves, top to bottom."""
+        rows = self.rows_of(idx)
+        R = len(rows)
+        tables = []
+        i = 0
+        while i < R:
+            if rows[i].size < 2:
+                i += 1
+                continue
+            j = i
+            while j < R and rows[j].size >= 2:
+                j += 1
+            if j - i >= 3 and self.is_table(np.concatenate(rows[i:j]), 3):
+                tables.append((i, j))
+            i = j
+        if not tables:
+            self.leaf(idx)
+            return
+        at = 0
+        for a, b in tables:
+            if at < a:
+                self.leaf(np.concatenate(rows[at:a]))
+            self.leaf(np.concatenate(rows[a:b]), True)
+            at = b
+        if at < R:
+            self.leaf(np.concatenate(rows[at:]))
 
 
 def reading_order(boxes: np.ndarray, col_gap: float = 1.2, block_gap: float = 0.9, min_col_lines: int = 3,
@@ -217,6 +278,7 @@ def reading_order(boxes: np.ndarray, col_gap: float = 1.2, block_gap: float = 0.
         return e + (np.zeros((0,), bool),) if with_tables else e
     c = _Cutter(boxes, col_gap, block_gap, min_col_lines, text_aspect)
     c.cut(np.arange(n))
+    c.tables_across_leaves()
     if with_tables:
         return np.asarray(c.order, dtype=np.int64), c.block_of, np.asarray(c.table_block, bool)[c.block_of]
     return np.asarray(c.order, dtype=np.int64), c.block_of

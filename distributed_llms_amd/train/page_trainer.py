@@ -253,6 +253,11 @@ def rec_batch(pages, model: CRNN, device, max_lines=64, jitter=0.12, angle_jitte
             # detector boxes are not pixel-exact: jitter every side by a fraction of the line height, and the angle
             # by what the second-moment estimate is off on a short line
             j = np.random.uniform(-jitter, jitter, size=4) * r[3]
+            if truth.layout == "table" and np.random.rand() < 0.6:
+                # the detector's box of a cell often reaches over the ruling line next to it: crops that start or end
+                # with a piece of a rule must read as the cell's text alone
+                j[0] -= np.random.uniform(0.0, 0.7) * r[3]
+                j[2] += np.random.uniform(0.0, 0.7) * r[3]
             cx, cy = r[0] + 0.5 * (j[0] + j[2]), r[1] + 0.5 * (j[1] + j[3])
             w, h = r[2] + (j[2] - j[0]), r[3] + (j[3] - j[1])
             if np.random.rand() < 0.6:

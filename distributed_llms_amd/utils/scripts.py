@@ -82,6 +82,18 @@ def _short_foreign(word: str, dom: str) -> bool:
     return 0 < len(letters) <= 3 and all(c in table for c in letters)
 
 
+# letters a digit can be taken for; inside a token that is otherwise digits and punctuation they are read as the digit
+_DIGIT_TWINS = str.maketrans({"б": "6", "З": "3", "з": "3", "О": "0", "о": "0", "O": "0", "o": "0", "l": "1", "I": "1",
+                              "i": "1", "Ь": "6", "ь": "6"})
+
+
+def _numeric_token(word: str) -> bool:
+    """At least two digits, and every letter in the token has a digit twin ("4б18.89", "2O24")."""
+    digits = sum(c.isdigit() for c in word)
+    letters = [c for c in word if c.isalpha()]
+    return digits >= 2 and 0 < len(letters) <= digits and all(ord(c) in _DIGIT_TWINS for c in letters)
+
+
 def resolve_scripts(text: str, hint: Optional[str] = None) -> str:
     """Decoded classes -> code points.  ``hint``: the script of the surrounding text (a page or document majority) for
     lines that consist of shared shapes only."""
@@ -94,6 +106,9 @@ def resolve_scripts(text: str, hint: Optional[str] = None) -> str:
         return text
     out = []
     for word in text.split(" "):
+        if _numeric_token(word):
+            out.append(word.translate(_DIGIT_TWINS))
+            continue
         cyr, grk, lat = _counts(word)
         if cyr and cyr >= max(grk, lat):
             word = word.translate(_TO_CYR)
