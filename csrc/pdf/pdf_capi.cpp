@@ -520,6 +520,39 @@ long long dlpdf_image_decode(void* hp, int page, int idx, uint8_t* dst, size_t d
   }
 }
 
+// Bilevel images (CCITT fax, 1-bit Flate) as PACKED bits: rows of (width + 7) / 8 bytes, most significant bit first, a
+// set bit = white (255) once /Decode inversion is applied.  The caller uploads the 1.1 MB of an A4 page at 300 DPI
+// and expands it on the GPU instead of writing and uploading 8.7 MB of bytes.  Returns the byte count, or a negative
+// code (-6: not a plain bilevel image - use dlpdf_image_decode).
+long long dlpdf_image_decode_bits(void* hp, int page, int idx, uint8_t* dst, size_t dst_len) {
+  Handle* h = (Handle*)hp;
+  if (!h || page < 0 || (size_t)page >= h->pages.size()) return -1;
+  ImageDesc im;
+  {
+    std::lock_guard<std::mutex> g(h->mu);
+    analyze_page(h, page);
+    const PageCache& pc = h->pages[page];
+    if (idx < 0 || (size_t)idx >= pc.images.size()) return -2;
+    im = pc.images[idx];
+  }
+  if (im.codec != 0) return -3;
+  if (im.bpc != 1 || im.ncomp != 1 || im.indexed || im.mask) return -6;
+  try {
+    std::string raw = run_filters(h->doc->data(), im);
+    const size_t rowbytes = ((size_t)im.width + 7) / 8, need = rowbytes * im.height;
+    if (dst_len < need) return -4;
+    if (raw.size() < need) raw.resize(need, im.invert ? (char)0xFF : 0);     // truncated: pad with paper
+    if (im.invert) {
+      for (size_t k = 0; k < need; ++k) dst[k] = (uint8_t)~(uint8_t)raw[k];
+    } else {
+      memcpy(dst, raw.data(), need);
+    }
+    return (long long)need;
+  } catch (const std::exception&) {
+    return -5;
+  }
+}
+
 struct DlpdfClassify {
   int32_t n_pages, is_text;          // is_text: 1 = born-digital (text branch), 0 = needs OCR
   int32_t pages_with_text, pages_image_dominant;

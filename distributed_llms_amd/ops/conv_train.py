@@ -129,7 +129,7 @@ class _ConvNHWC(torch.autograd.Function):
 class _ConvFirstLayer(torch.autograd.Function):
     """First convolution of a model: image in (no gradient wanted for it), few input channels.  Forward = the
     inference kernels on the image padded to 8 channels; weight gradient = im2col of the padded image ([N, Ho Wo, kh kw 8]:
-    small, 16-byte pixels) times the output gradient, one batched GEMM summed over the batch."""
+    small, 16-byte pixels) times the output gradient on the split-K weight-gradient kernel."""
 
     @staticmethod
     def forward(ctx, x, weight, stride, padding):
@@ -151,9 +151,14 @@ class _ConvFirstLayer(torch.autograd.Function):
         N, Ho, Wo = dy.shape[0], dy.shape[1], dy.shape[2]
         xp = F.pad(x8, (0, 0, pw, pw, ph, ph))
         taps = [xp[:, r : r + sh * (Ho - 1) + 1 : sh, c : c + sw * (Wo - 1) + 1 : sw] for r in range(kh) for c in range(kw)]
-        cols = torch.cat(taps, dim=3).reshape(N, Ho * Wo, kh * kw * 8)
-        g = dy.reshape(N, Ho * Wo, cout)
-        dw = torch.bmm(cols.transpose(1, 2), g).sum(0, dtype=torch.float32)     # [kh kw 8, Cout]
+        cols = torch.cat(taps, dim=3).reshape(N * Ho * Wo, kh * kw * 8)
+        g = dy.reshape(N * Ho * Wo, cout)
+        if dy.is_cuda:
+            from .linear_train import weight_grad        # the split-K weight-gradient kernel: no library GEMM
+
+            dw = weight_grad(cols, g).t()                                        # [kh kw 8, Cout]
+        else:
+            dw = cols.float().t() @ g.float()
         dw = dw.reshape(kh, kw, 8, cout)[:, :, :cin].permute(3, 2, 0, 1)         # [Cout, Cin, kh, kw]
         return None, dw.contiguous().to(wdtype), None, None
 

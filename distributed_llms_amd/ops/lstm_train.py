@@ -78,7 +78,9 @@ class _BiLSTMRecurrence(torch.autograd.Function):
             hp = [torch.cat([z, y[:, :-1, :H]], 1)]
             if ndir == 2:
                 hp.append(torch.cat([y[:, 1:, H:], z], 1))      # y is zero at t >= len, so t = len-1 sees h_prev = 0
-            dw = torch.stack([(dg[:, :, d * G:(d + 1) * G].reshape(N * T, G).t() @ hp[d].reshape(N * T, H)).float()
+            from .linear_train import weight_grad        # the split-K weight-gradient kernel: no library GEMM
+
+            dw = torch.stack([weight_grad(hp[d].reshape(N * T, H), dg[:, :, d * G:(d + 1) * G].reshape(N * T, G))
                               for d in range(ndir)], 0).to(w_hh.dtype)
         return dg, dw, None
 

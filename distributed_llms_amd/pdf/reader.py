@@ -96,6 +96,8 @@ def lib() -> ctypes.CDLL:
             l.dlpdf_free.restype = None
             l.dlpdf_image_decode.argtypes = [vp, i, i, vp, sz]
             l.dlpdf_image_decode.restype = ctypes.c_longlong
+            l.dlpdf_image_decode_bits.argtypes = [vp, i, i, vp, sz]
+            l.dlpdf_image_decode_bits.restype = ctypes.c_longlong
             l.dlpdf_classify.argtypes = [vp, ctypes.POINTER(_Classify)]
             l.dlpdf_fast_inflate.argtypes = [vp, sz, vp, sz]
             l.dlpdf_fast_inflate.restype = ctypes.c_longlong
@@ -352,6 +354,22 @@ class PdfDocument:
         if rc < 0:
             raise PdfError(f"image decode failed (code {rc})")
         return out.reshape(-1)[:need].reshape(shape)
+
+    def decode_image_bits(self, im: ImageInfo, out: Optional[np.ndarray] = None) -> Optional[np.ndarray]:
+        """A plain bilevel image as packed bits: uint8 [H, (W + 7) // 8], most significant bit first, set bit = white.
+        None when the image is not one (more than one bit per sample, a palette, a mask): use ``decode_image``."""
+        if im.codec != CODEC_RAW or im.bpc != 1 or im.out_channels != 1:
+            return None
+        rowbytes = (im.width + 7) // 8
+        if out is None:
+            out = np.empty((im.height, rowbytes), dtype=np.uint8)
+        assert out.dtype == np.uint8 and out.size >= im.height * rowbytes and out.flags["C_CONTIGUOUS"]
+        rc = lib().dlpdf_image_decode_bits(self._h, im.page, im.index, out.ctypes.data, out.size)
+        if rc == -6:
+            return None
+        if rc < 0:
+            raise PdfError(f"image decode failed (code {rc})")
+        return out.reshape(-1)[: im.height * rowbytes].reshape(im.height, rowbytes)
 
     def classify(self) -> Classification:
         c = _Classify()

@@ -193,6 +193,15 @@ _DIGITS = re.compile(r"\d+")
 _SPACES = re.compile(r"\s+")
 
 
+_NOT_WORD = re.compile(r"[^\w#]+", re.UNICODE)
+
+
+def _running_key(text: str) -> str:
+    """What must repeat for a margin line to count as running: its letters, with every number as one '#' and
+    punctuation and spacing ignored ("- 12 -", "-13-" and "14" are the same line; so are "Page 3 of 40" and "page 4 of 40")."""
+    return _NOT_WORD.sub(" ", _DIGITS.sub("#", text.lower())).strip()
+
+
 def drop_running_lines(content: List[dict], n_pages: int) -> Tuple[List[dict], List[dict]]:
     """Running headers and footers: a line in the top / bottom margin band whose text - digits aside, so that page
     numbers count - shows up on three or more pages of the document, or on two when those are at least 40 % of it.
@@ -204,13 +213,13 @@ def drop_running_lines(content: List[dict], n_pages: int) -> Tuple[List[dict], L
     for it in content:
         m = it.get("margin")
         if m:
-            key = (m, _SPACES.sub(" ", _DIGITS.sub("#", it["text"].lower())).strip())
+            key = (m, _running_key(it["text"]))
             where.setdefault(key, set()).add(it["page_idx"])
     running = {k for k, pages in where.items() if len(pages) >= 3 or (len(pages) >= 2 and len(pages) >= 0.4 * n_pages)}
     kept, dropped = [], []
     for it in content:
         m = it.pop("margin", None)
-        if m and (m, _SPACES.sub(" ", _DIGITS.sub("#", it["text"].lower())).strip()) in running:
+        if m and (m, _running_key(it["text"])) in running:
             dropped.append({"type": "header" if m == "top" else "footer", "text": it["text"], "page_idx": it["page_idx"]})
         else:
             kept.append(it)
@@ -429,6 +438,11 @@ class DocumentPipeline:
         elif im.codec == reader.CODEC_RAW:
             shape = (im.height, im.width) if im.out_channels == 1 else (im.height, im.width, 3)
             if self.engine.on_gpu:
+                if im.bpc == 1 and im.out_channels == 1 and getattr(self.engine, "takes_bits", False):
+                    # bilevel page: upload the packed bits (1.1 MB for A4 at 300 DPI), expand on the GPU
+                    tb = torch.empty((im.height, (im.width + 7) // 8), dtype=torch.uint8, pin_memory=self._pin)
+                    if doc.decode_image_bits(im, tb.numpy()) is not None:
+                        return PageImage(None, doc_id, i, prior, bits=(tb, im.width))
                 t = torch.empty(shape, dtype=torch.uint8, pin_memory=self._pin)
                 doc.decode_image(im, t.numpy())
                 return PageImage(t, doc_id, i, prior)

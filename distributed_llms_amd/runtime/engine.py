@@ -49,8 +49,10 @@ def _round_up(v: int, m: int) -> int:
 class PageImage:
     """One page raster.
 
-    Either ``image`` (uint8 [H, W] or [H, W, 3] tensor, host - ideally pinned - or device) or
-    ``encoded`` = (JPEG stream bytes as uint8 ndarray, its ``JpegScan``) for the GPU JPEG decoder."""
+    One of ``image`` (uint8 [H, W] or [H, W, 3] tensor, host - ideally pinned - or device),
+    ``encoded`` = (JPEG stream bytes as uint8 ndarray, its ``JpegScan``) for the GPU JPEG decoder, or
+    ``bits`` = (packed bilevel rows as uint8 [H, (W + 7) // 8] tensor, most significant bit first, set bit = white;
+    width in pixels), expanded on the GPU."""
 
     image: Optional[torch.Tensor] = None
     doc_id: str = ""
@@ -58,11 +60,14 @@ class PageImage:
     layout_prior: Optional[np.ndarray] = None  # [n, 4] x0,y0,x1,y1 in page pixels (see module docstring)
     encoded: Optional[tuple] = None
     rotation: int = 0          # the page's /Rotate: degrees clockwise the stored raster must be turned to read upright
+    bits: Optional[tuple] = None
 
     @property
     def raster_hw(self) -> Tuple[int, int]:
         if self.image is not None:
             return int(self.image.shape[0]), int(self.image.shape[1])
+        if self.bits is not None:
+            return int(self.bits[0].shape[0]), int(self.bits[1])
         info = self.encoded[1].info
         return int(info.height), int(info.width)
 
@@ -229,6 +234,8 @@ class OcrEngine:
         self._graphs: Dict[Tuple[int, int, int], "_RecGraph"] = {}
         cs = getattr(self.rec, "charset", "")
         self._lut = None
+        self._bit_lut = None
+        self.takes_bits = self.on_gpu          # bilevel pages may arrive as packed bits (PageImage.bits)
         if cs and all(ord(c) < 0x10000 and not 0xD800 <= ord(c) < 0xE000 for c in cs):
             # class id -> code point (id 0 = CTC blank): strings are built by one gather + one UTF-32 decode per line
             self._lut = np.frombuffer(("\0" + cs).encode("utf-32-le"), dtype=np.uint32)
@@ -259,7 +266,16 @@ class OcrEngine:
         ctx = torch.cuda.stream(st) if self.on_gpu else _null_ctx()
         with ctx:
             srcs: List[Optional[torch.Tensor]] = [None] * B
-            enc = [i for i, p in enumerate(pages) if p.image is None]
+            for i, p in enumerate(pages):
+                if p.bits is not None:
+                    # bilevel page: 8 pixels per uploaded byte, expanded by one table look-up on the device
+                    packed = p.bits[0].to(self.device, non_blocking=True)
+                    if self._bit_lut is None:
+                        v = torch.arange(256, dtype=torch.int32).view(256, 1) >> torch.arange(7, -1, -1, dtype=torch.int32).view(1, 8)
+                        self._bit_lut = ((v & 1) * 255).to(torch.uint8).to(self.device)
+                    img = self._bit_lut[packed.view(-1).long()].view(packed.shape[0], packed.shape[1] * 8)
+                    srcs[i] = img if img.shape[1] == p.bits[1] else img[:, : p.bits[1]].contiguous()
+            enc = [i for i, p in enumerate(pages) if p.image is None and p.bits is None]
             if enc:
                 if self.on_gpu:
                     dec = jpeg_ops.decode_jpeg_batch_gpu([pages[i].encoded[0] for i in enc],

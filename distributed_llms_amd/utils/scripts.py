@@ -73,13 +73,23 @@ def line_script(text: str) -> str:
     return "latin"
 
 
+# short English words that are spelled with twin letters only: left alone inside a Russian / Greek line
+_SHORT_ENGLISH = frozenset(
+    "a an am at be by do go he if in is it me my no of on or so to up us we an and any are ask but buy can car cut day "
+    "eat end eye for get got guy her him his hot how its key man map may men met net new nor not now one our out own "
+    "pay per put ran run saw say see set she sit six ten the too top try two use war was way who why win won yes yet you "
+    "pm km cm mm ok tv pc api cpu gpu url pdf ocr".split())
+
+
 def _short_foreign(word: str, dom: str) -> bool:
     """A word of at most three letters, in a line of the other alphabet, all of whose letters have a (near-)twin
-    there: the italic "no", "om", "u" of a Russian line are по, от, и.  Longer words stay as read - an English word
-    inside a Russian sentence is far more likely than five twins in a row."""
+    there: the italic "om", "u", "mo" of a Russian line are от, и, то.  Common short English words ("no", "one", "at") and
+    longer words stay as read - an English word inside a Russian sentence is far more likely than five twins in a row."""
     table = _LATIN_TO_CYR_SOFT if dom == "cyrillic" else _LATIN_TO_GRK_SOFT
     letters = [c for c in word if c.isalpha()]
-    return 0 < len(letters) <= 3 and all(c in table for c in letters)
+    if not 0 < len(letters) <= 3 or "".join(letters).lower() in _SHORT_ENGLISH:
+        return False
+    return all(c in table for c in letters)
 
 
 # letters a digit can be taken for; inside a token that is otherwise digits and punctuation they are read as the digit

@@ -240,7 +240,14 @@ def test_ccitt_group4_scans_decode_exactly(hw):
             want = ((pg >= 128) * 255).astype(np.uint8)
             assert got.shape == want.shape
             assert np.array_equal(got, want), f"page {i}: {(got != want).sum()} pixels differ"
+            # the same page as packed bits (what goes to the GPU: 8 pixels per byte, set bit = white)
+            bits = doc.decode_image_bits(im)
+            assert bits is not None and bits.shape == (H, (W + 7) // 8)
+            assert np.array_equal(np.unpackbits(bits, axis=1)[:, :W] * 255, want)
         assert not doc.classify().is_text
+    # a gray page is no bilevel image: the packed path declines
+    with reader.PdfDocument(synth.make_scanned_pdf([pages[0]], codec="flate", dpi=72)) as doc:
+        assert doc.decode_image_bits(doc.main_image(0)) is None
 
 
 def test_ccitt_damaged_data_never_crashes():

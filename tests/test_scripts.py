@@ -27,7 +27,8 @@ def test_latin_text_is_left_alone():
 def test_italic_twins_are_resolved_by_context():
     """Italic Cyrillic draws и, п, т as u, n, m; italic Greek draws alpha as a and nu as v.  Inside a word (or, for
     very short words, a line) of that alphabet they are read as its letters; English words in the line stay."""
-    assert S.resolve_scripts("Этo no гpyппe om ниx u mo") == "Это по группе от них и то"
+    assert S.resolve_scripts("Этo пo гpyппe om ниx u mo") == "Это по группе от них и то"
+    assert S.resolve_scripts("Этo no one at гpyппe") == "Это no one at группе"          # short English words stay
     assert S.resolve_scripts("Пpивeт Worker and Queue") == "Привет Worker and Queue"
     assert S.resolve_scripts("Όταv τηv a και va") == "Όταν την α και να"
     # a digit read as its look-alike letter inside a number
