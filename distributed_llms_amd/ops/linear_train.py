@@ -31,19 +31,32 @@ def _pad_to(t: torch.Tensor, dim: int, mult: int) -> torch.Tensor:
 
 
 def weight_grad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
-    """dW [N, K] fp32 = dy^T x for x [M, K], dy [M, N] (bf16, any strides) on the split-K weight-gradient kernel: a
-    1 x 1 "convolution" over one image row of M pixels (the kernel's work units are runs of 64 consecutive pixels of a
-    row); both channel counts are padded to multiples of 64 with zeros.
+    """dW [N, K] fp32 = dy^T x for x [M, K], dy [M, N] (bf16, any strides) on the split-K weight-gradient kernel.
 
-    Measured against the alternative of transposing both operands and running the GEMM kernels (whose reduction index
-    must be the contiguous one): the two transposes of a 32 768 x 2048 gradient cost more than the GEMM saves - 16.8 k
-    samples/s against 17.4 k for the recogniser's training step (the library GEMM it replaces: 20.3 k)."""
+    That kernel gives a workgroup dW[64 output channels][up to 9 taps][64 input channels] and walks over runs of 64
+    pixels of an image row; per MFMA K-step a wave reads 4 dY fragments plus ONE input fragment per tap.  A plain 1 x 1
+    "convolution" over one row of M pixels would use one tap: 5 LDS fragment reads per 4 MFMAs and dy fetched once per
+    64 input channels.  So the K input features are laid out as kh x kw TAPS of K / (kh kw) channels instead:
+
+        X'[r][kw p + s][c] = x[p][((r kw + s) C' + c)]      (an image of kh rows and kw M pixels, C' = K / (kh kw))
+
+    convolved with a kh x kw filter at stride (1, kw) and no padding has exactly one output row of M pixels, and its
+    weight gradient dW'[co][r][s][c] is dW[co][(r kw + s) C' + c] - up to six taps per workgroup (kh <= 3, kw <= 2 is
+    what the kernel's patch buffer holds at stride 2): 10 fragment reads per 24 MFMAs and a sixth of the dy traffic.
+    Channel counts are padded to multiples of 64 with zeros.
+
+    Measured against transposing both operands and running the GEMM kernels (whose reduction index must be the
+    contiguous one): the two transposes of a 32 768 x 2048 gradient cost more than the GEMM saves."""
     M, K = x.shape
     N = dy.shape[1]
-    xp = _pad_to(x.to(torch.bfloat16), 1, 64).contiguous()
+    xp = _pad_to(x.to(torch.bfloat16), 1, 64)
     dyp = _pad_to(dy.to(torch.bfloat16), 1, 64).contiguous()
-    dwp = conv_wgrad(xp.view(1, 1, M, xp.shape[1]), dyp.view(1, 1, M, dyp.shape[1]), 1, 1, (1, 1), (0, 0))
-    return dwp.view(dyp.shape[1], xp.shape[1])[:N, :K]
+    blocks = xp.shape[1] // 64
+    kh, kw = next(((a, b) for a, b in ((3, 2), (2, 2), (3, 1), (2, 1)) if blocks % (a * b) == 0), (1, 1))
+    cp = xp.shape[1] // (kh * kw)
+    ximg = xp.reshape(M, kh, kw, cp).permute(1, 0, 2, 3).reshape(1, kh, M * kw, cp).contiguous()
+    dwp = conv_wgrad(ximg, dyp.view(1, 1, M, dyp.shape[1]), kh, kw, (1, kw), (0, 0))        # [N64, kh, kw, C']
+    return dwp.reshape(dyp.shape[1], xp.shape[1])[:N, :K]
 
 
 class _LinearBF16(torch.autograd.Function):
