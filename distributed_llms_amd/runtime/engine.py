@@ -37,7 +37,7 @@ from ..ops import dbpost
 from ..ops import jpeg as jpeg_ops
 from ..ops import lstm as lstm_ops
 from ..ops import resample as rs
-from ..utils.scripts import resolve_scripts
+from ..utils.scripts import resolve_scripts, script_counts
 from . import layout
 
 
@@ -111,6 +111,29 @@ class PageResult:
 
     def text(self) -> str:
         return "\n".join(l.text for l in self.lines if l.text)
+
+
+def _apply_page_script(lines: List[TextLine]) -> None:
+    """Lines made only of letters that Latin shares with Cyrillic / Greek ("О НАС", "ТЕМА", a lone "а") cannot tell
+    their alphabet themselves: on a page where at least two lines, and most of the lines that can tell, are Cyrillic
+    (Greek), they are read as that alphabet too."""
+    votes = {"cyrillic": 0, "greek": 0, "latin": 0}
+    for ln in lines:
+        if ln.kind == "equation" or not ln.text:
+            continue
+        cyr, grk, lat = script_counts(ln.text)
+        if cyr > max(grk, lat):
+            votes["cyrillic"] += 1
+        elif grk > max(cyr, lat):
+            votes["greek"] += 1
+        elif lat:                                  # letters only Latin has; a line of shared shapes does not vote
+            votes["latin"] += 1
+    page = max(("cyrillic", "greek"), key=lambda k: votes[k])
+    if votes[page] < 2 or votes[page] <= votes["latin"]:
+        return
+    for ln in lines:
+        if ln.kind != "equation" and ln.text:
+            ln.text = resolve_scripts(ln.text, hint=page)
 
 
 @dataclass
@@ -858,6 +881,8 @@ class OcrEngine:
                 if crop is not None:
                     r.figures.append(Figure(tuple(float(v) for v in fg[k, :4]), int(fg[k, 4]), crop.numpy()))
             pos += b4.shape[0]
+            if getattr(self.rec, "multi_script", False):
+                _apply_page_script(r.lines)
             self.lines_done += len(r.lines)
             results.append(r)
         self.pages_done += len(results)

@@ -61,6 +61,11 @@ def _counts(word: str):
     return cyr, grk, lat
 
 
+def script_counts(text: str):
+    """(letters only Cyrillic has, letters only Greek has, letters only Latin has) in ``text``."""
+    return _counts(text)
+
+
 def line_script(text: str) -> str:
     """``latin``, ``cyrillic`` or ``greek``: the alphabet most of the unambiguous letters of a decoded line belong to."""
     if text.isascii():

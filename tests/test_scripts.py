@@ -50,3 +50,18 @@ def test_recogniser_grows_to_the_multi_script_set_and_reads_it_back():
     m2 = CRNN()
     m2.load_state_dict(m.state_dict())                                  # a 258-row checkpoint brings its character set
     assert m2.charset == MULTI_CHARSET
+
+
+def test_page_majority_decides_lines_of_shared_letters():
+    """"О НАС", "ТЕМА", a lone "а": every letter has a Latin twin, so the line cannot tell its alphabet; on a page whose
+    telling lines are mostly Cyrillic it is read as Cyrillic, on a Latin page it stays as it is."""
+    from distributed_llms_amd.runtime.engine import TextLine, _apply_page_script
+
+    texts = ["О НАС", "Привет, мир и все", "Это тест системы", "Москва и область", "ТЕМА", "Worker and Queue", "2024", "а"]
+    lines = [TextLine((0, 0, 1, 1), S.resolve_scripts(S.to_visual(t)), 1.0) for t in texts]
+    assert lines[0].text == "O HAC" and lines[4].text == "TEMA"            # read alone they are Latin
+    _apply_page_script(lines)
+    assert [ln.text for ln in lines] == texts
+    latin = [TextLine((0, 0, 1, 1), t, 1.0) for t in ["The cop saw", "A MAP", "Привет one", "HOME"]]
+    _apply_page_script(latin)
+    assert [ln.text for ln in latin] == ["The cop saw", "A MAP", "Привет one", "HOME"]
