@@ -84,14 +84,22 @@ def main():
     ap.add_argument("--burst-poll-ms", type=float, default=10.0, help="status polling interval of the concurrent clients")
     ap.add_argument("--num-gpus", type=int, default=-1)
     ap.add_argument("--force-pool", action="store_true", help="use the worker-process pool even with one GPU")
-    ap.add_argument("--server", choices=["dlamd", "uvicorn"], default="dlamd",
+    ap.add_argument("--frontends", type=int, default=2, help="--server serve: front-end processes on the port")
+    ap.add_argument("--server", choices=["dlamd", "uvicorn", "serve"], default="dlamd",
                     help="HTTP server in front of the application: api/httpd.py (default) or uvicorn")
     args = ap.parse_args()
 
     # the service runs as its own process, exactly as deployed: uvicorn + the module-level ASGI app
     env = dict(os.environ, OCR_NUM_GPUS=str(args.num_gpus), OCR_OUTPUT_DIR="/tmp/ocr_bench_out",
                OCR_FORCE_POOL="1" if args.force_pool else "0", OCR_DOTENV="/nonexistent")
-    if args.server == "uvicorn":
+    if args.server == "serve":
+        # the node launcher: front-end processes on one port, every one connected to the GPU worker server(s) over Unix
+        # sockets; uploads received into shared memory, results returned packed (api/serve.py)
+        env.pop("OCR_NUM_GPUS")
+        env.pop("OCR_FORCE_POOL")
+        cmd = [sys.executable, "-m", "distributed_llms_amd.api.serve", "--host", "127.0.0.1", "--port", str(args.port),
+               "--frontends", str(args.frontends), "--embedded-redis"]
+    elif args.server == "uvicorn":
         cmd = [sys.executable, "-m", "uvicorn", "distributed_llms_amd.api.asgi:app", "--host", "127.0.0.1",
                "--port", str(args.port), "--log-level", "warning"]
     else:
