@@ -651,6 +651,47 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(const ConvA
     }
     return;
   }
+  // Replicate store (the FPN's p3 / p4 / p5 written f x f times into the concat buffer at 1/4 scale): written straight
+  // from the accumulators every copy is an 8-byte piece of a 128-byte pixel row - 64 partial-line writes per value for
+  // p5.  The tile is put into LDS once (bias and activation applied, bf16) and every thread then copies 16-byte chunks,
+  // eight consecutive lanes per destination pixel: whole 128-byte lines, half as many store instructions.
+  if (p.out_mode == 2 && !p.y_f32 && p.res_mode == 0 && BN == 64 && ((p.y_cstride | p.y_coff | p.Cout) & 7) == 0) {
+    constexpr int ROWB = 144;                       // 128 bytes of channels + 16: consecutive pixel rows start 4 banks apart
+    static_assert(BM * ROWB <= PH * PW * 128, "the staged tile must fit the patch buffer");
+    __syncthreads();                                // every wave is done reading the last patch
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      const int nl = wn * TN + i * 16 + fq * 4;
+      const int n = n0 + nl;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias && n < p.Cout) bv = f32x4{p.bias[n], p.bias[n + 1], p.bias[n + 2], p.bias[n + 3]};
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        const int lp = wm * TM + j * 16 + frow;
+        const bf16x4 o = {(bf16_t)dlamd_act(acc[i][j][0] + bv[0], p.act), (bf16_t)dlamd_act(acc[i][j][1] + bv[1], p.act),
+                          (bf16_t)dlamd_act(acc[i][j][2] + bv[2], p.act), (bf16_t)dlamd_act(acc[i][j][3] + bv[3], p.act)};
+        *reinterpret_cast<bf16x4*>(smem + lp * ROWB + nl * 2) = o;
+      }
+    }
+    __syncthreads();
+    const int f = p.out_f;
+    const int chunks = min(BN, p.Cout - n0) >> 3;   // valid 16-byte chunks of a pixel row
+    bf16_t* yp = reinterpret_cast<bf16_t*>(p.y);
+    const int total = BM * 8 * f * f;
+    for (int q = tid; q < total; q += NT) {
+      const int c = q & 7;
+      const int rest = q >> 3;
+      const int lp = rest % BM, rep = rest / BM;
+      const int py = lp / TW, px = lp - py * TW;
+      const int oy = oy0 + py, ox = ox0 + px;
+      if (c >= chunks || oy >= p.Ho || ox >= p.Wo) continue;
+      const int dy = rep / f, dx = rep - dy * f;
+      const long long pix = ((long long)b * (f * p.Ho) + f * oy + dy) * (f * p.Wo) + f * ox + dx;
+      *reinterpret_cast<u32x4*>(yp + pix * p.y_cstride + p.y_coff + n0 + c * 8) =
+          *reinterpret_cast<const u32x4*>(smem + lp * ROWB + c * 16);
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < FM; ++j) {
     const int lp = wm * TM + j * 16 + frow;
