@@ -251,3 +251,23 @@ def test_running_headers_and_footers_leave_the_content_list():
     assert [it["text"] for it in res2.content_list] == texts and res2.discarded == res.discarded
     one = assemble_document("doc", "ocr", pages[:1])
     assert any("Annual Report" in it["text"] for it in one.content_list) and not one.discarded
+
+
+def test_table_in_a_born_digital_pdf_becomes_a_table_item():
+    """The text-layer branch runs the same layout analysis: positioned cells of a born-digital page (emitted row by
+    row, each cell its own text-showing operator) come back as one table with its rows and columns; header and title
+    stay outside of it."""
+    from distributed_llms_amd.runtime.document import page_content_items
+
+    cols = [["Item", "Paper A4", "Toner black", "Stapler", "Binder"], ["Qty", "12", "3", "1", "40"],
+            ["Price", "4.50", "61.00", "8.99", "1.20"], ["Total", "54.00", "183.00", "8.99", "48.00"]]
+    pdf = synth.make_text_pdf_columns(cols, title="Order 2024-117", header="ACME Office Supplies")
+    with reader.PdfDocument(pdf) as doc:
+        pr = text_layer_page(doc, 0, "t")
+    items = page_content_items(pr)
+    tabs = [it for it in items if it["type"] == "table"]
+    assert len(tabs) == 1, [(it["type"], it.get("text")) for it in items]
+    assert tabs[0]["cells"] == [[c[r] for c in cols] for r in range(5)]
+    assert "<td>Toner black</td><td>3</td><td>61.00</td><td>183.00</td>" in tabs[0]["table_body"]
+    texts = [it["text"] for it in items if it["type"] == "text"]
+    assert "Order 2024-117" in texts and "ACME Office Supplies" in texts
