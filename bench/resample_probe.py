@@ -33,6 +33,13 @@ def main():
     ms = timed(lambda: rs.resample_items_gpu(items, B, 1344, 960))
     floor = (B * 3508 * 2480 + B * 1344 * 960 * 16) / 5e12 * 1e3
     print(json.dumps({"shape": "25 pages 3508x2480 -> 1344x950 (bucket 960)", "ms": round(ms, 4), "hbm_floor_ms": round(floor, 4)}), flush=True)
+    # the fused form the engine runs: resample + first convolution (3 -> 32 for the detector, 3 -> 64 for the recogniser)
+    w32 = (torch.randn(32, 3, 3, 8, device=dev) * 0.1).to(torch.bfloat16)
+    w64 = (torch.randn(64, 3, 3, 8, device=dev) * 0.1).to(torch.bfloat16)
+    b32, b64 = torch.zeros(32, device=dev), torch.zeros(64, device=dev)
+    ms = timed(lambda: rs.resample_stem_items_gpu(items, B, 1344, 960, rs.IMAGENET_MEAN, rs.IMAGENET_STD, w32, b32))
+    floor = (B * 3508 * 2480 + B * 672 * 480 * 64) / 5e12 * 1e3
+    print(json.dumps({"shape": "fused stem, 25 pages -> 672x480x32", "ms": round(ms, 4), "hbm_floor_ms": round(floor, 4)}), flush=True)
     rng = np.random.default_rng(0)
     for wb, n in ((1536, 600), (2048, 375), (512, 100)):
         regs = []
@@ -46,6 +53,9 @@ def main():
         floor = (n * 48 * wb * 16 + n * 60 * wb * 1.25) / 5e12 * 1e3
         print(json.dumps({"shape": f"{n} crops -> 48x{wb}" + (" slanted" if len(sys.argv) > 1 else ""), "ms": round(ms, 4),
                           "hbm_floor_ms": round(floor, 4)}), flush=True)
+        ms = timed(lambda: rs.resample_stem_items_gpu(items, n, 48, wb, rs.HALF_MEAN, rs.HALF_STD, w64, b64))
+        floor = (n * 24 * (wb // 2) * 128 + n * 60 * wb * 1.25) / 5e12 * 1e3
+        print(json.dumps({"shape": f"fused stem, {n} crops -> 24x{wb // 2}x64", "ms": round(ms, 4), "hbm_floor_ms": round(floor, 4)}), flush=True)
 
 
 if __name__ == "__main__":
