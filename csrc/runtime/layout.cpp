@@ -93,16 +93,44 @@ struct Cutter {
   // of all rows falling into common columns (the whitespace between the columns runs through every row, at least 0.6
   // line heights wide), no row with two cells in one column, every column filled in at least half of the rows, and at
   // most one column of long text (two columns of running text whose lines happen to share baselines are not a table).
+  // Column boundaries of a would-be table: the middles of the x-intervals, at least 0.6 line heights wide, that at
+  // most ``tol`` cells reach into (one over-long cell that runs up to its neighbour must not glue two columns of an
+  // eight-row table together), with cells on both sides.
+  std::vector<double> table_cuts(const std::vector<int>& idx, int tol) const {
+    std::vector<double> edges;
+    for (int i : idx) { edges.push_back(b[i].x0); edges.push_back(b[i].x1); }
+    std::sort(edges.begin(), edges.end());
+    edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+    std::vector<double> cuts;
+    bool open = false;
+    double start = 0, end = 0;
+    for (size_t k = 0; k + 1 < edges.size(); ++k) {
+      const double a = edges[k], e = edges[k + 1];
+      int cover = 0;
+      for (int i : idx) cover += (b[i].x0 < e && b[i].x1 > a);
+      if (cover <= tol) {
+        if (!open) { open = true; start = a; }
+        end = e;
+      } else {
+        if (open && end - start >= 0.6 * h_med) {
+          bool left = false;
+          for (int i : idx) left |= b[i].x1 <= start + 1e-9;
+          if (left) cuts.push_back(0.5 * (start + end));
+        }
+        open = false;
+      }
+    }
+    return cuts;
+  }
+
   bool is_table(const std::vector<int>& idx, int min_rows) const {
     if ((int)idx.size() < 2 * min_rows) return false;
     for (int i : idx) if (b[i].y1 - b[i].y0 > 3.0 * h_med) return false;     // a figure or a rotated line: no cell
     auto rows = rows_of(idx);
     if ((int)rows.size() < min_rows) return false;
     for (auto& r : rows) if (r.size() < 2) return false;
-    std::vector<double> cuts;
-    for (auto& g : gaps<false>(idx)) if (g.width >= 0.6 * h_med) cuts.push_back(0.5 * (g.start + g.end));
+    std::vector<double> cuts = table_cuts(idx, rows.size() >= 6 ? 1 : 0);
     if (cuts.empty()) return false;
-    std::sort(cuts.begin(), cuts.end());
     const size_t C = cuts.size() + 1;
     std::vector<int> filled(C, 0);
     std::vector<std::vector<double>> aspect(C);
@@ -142,7 +170,7 @@ struct Cutter {
 
   // A side of a vertical cut counts as a column of running text when it holds several lines that are much wider than
   // tall: the median aspect reaches text_aspect, or - a column that also holds a table, whose many short cells pull
-  // the median down - at least a quarter of its boxes (and min_col_lines of them) are long lines (aspect >= 8).
+  // the median down - at least min_col_lines of its boxes are long lines (aspect >= 8; a column of a table has none).
   bool is_text_column(const std::vector<int>& idx) const {
     if ((int)idx.size() < min_col_lines) return false;
     std::vector<double> r;
@@ -152,7 +180,7 @@ struct Cutter {
       longs += r.back() >= 8.0;
     }
     if (median(r) >= text_aspect) return true;
-    return longs >= min_col_lines && 4 * longs >= (int)idx.size();
+    return longs >= min_col_lines;
   }
 
   std::vector<double> column_cuts(const std::vector<int>& idx) const {

@@ -576,7 +576,7 @@ def render_table_page(seed: int, size: Tuple[int, int] = A4_300DPI, rows: int = 
                 t = random_text(rng, 12) or "row"
             else:
                 t = ("%d.%02d" % (int(rng.integers(1, 5000)), int(rng.integers(100)))) if rng.random() < 0.7 else (random_text(rng, 8) or "n/a")
-            t = t[: max(3, int(cw / avg_char) - 3)].strip() or "x"
+            t = t[: max(3, int((cw - 2.5 * px) / avg_char))].strip() or "x"     # a typeset table keeps a gutter between cells
             put(margin + c * cw + px // 2, y, t)
             row.append(t)
         grid.append(row)

@@ -112,29 +112,39 @@ def table_item(grid: Sequence[Sequence[str]], page_idx: int, bbox: Sequence[floa
 
 def table_grid(cells: Sequence[TextLine]) -> List[List[str]]:
     """Cells of one table (row by row, left to right, as the layout analysis orders them) -> rows x columns of text.
-    A new row starts where x stops growing; the columns are the connected runs of the cells' x-extents, so a row that
-    lacks a cell gets an empty string in that column."""
+    A new row starts where x stops growing.  The columns are bounded as the layout analysis bounds them
+    (``runtime/layout.py::table_cuts``): by the x-intervals, at least 0.6 line heights wide, that at most ``tol`` cells
+    reach into - from six rows on one over-long cell may run up to its neighbour.  A cell belongs to the column its
+    left edge lies in; a row that lacks a cell gets an empty string there."""
+    import bisect
+
     rows: List[List[TextLine]] = []
     for c in cells:
         if rows and c.box[0] > rows[-1][-1].box[0]:
             rows[-1].append(c)
         else:
             rows.append([c])
-    spans = sorted((c.box[0], c.box[2]) for c in cells)
-    cols: List[List[float]] = []
-    for a, b in spans:
-        if cols and a <= cols[-1][1]:
-            cols[-1][1] = max(cols[-1][1], b)
-        else:
-            cols.append([a, b])
-    starts = [c[0] for c in cols]
-    import bisect
-
+    tol = 1 if len(rows) >= 6 else 0
+    hs = sorted(c.box[3] - c.box[1] for c in cells)
+    min_gap = 0.6 * hs[len(hs) // 2]
+    x0 = [c.box[0] for c in cells]
+    x1 = [c.box[2] for c in cells]
+    edges = sorted(set(x0) | set(x1))
+    cuts: List[float] = []
+    run = None                       # the current run of sparsely covered x-intervals
+    for a, e in zip(edges[:-1], edges[1:]):
+        cover = sum(1 for p, q in zip(x0, x1) if p < e and q > a)
+        if cover <= tol:
+            run = (a, e) if run is None else (run[0], e)
+            continue
+        if run is not None and run[1] - run[0] >= min_gap and any(q <= run[0] + 1e-9 for q in x1):
+            cuts.append(0.5 * (run[0] + run[1]))
+        run = None
     grid = []
     for r in rows:
-        out = [""] * len(cols)
+        out = [""] * (len(cuts) + 1)
         for c in r:
-            k = max(0, bisect.bisect_right(starts, c.box[0] + 1e-6) - 1)
+            k = bisect.bisect_right(cuts, c.box[0] + 1e-6)
             out[k] = (out[k] + " " + c.text.strip()).strip()
         grid.append(out)
     return grid

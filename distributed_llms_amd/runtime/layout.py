@@ -93,10 +93,31 @@ class _Cutter:
                 start = i
         return rows
 
+    def table_cuts(self, idx: np.ndarray, tol: int) -> List[float]:
+        """Column boundaries of a would-be table: the middles of the x-intervals, at least 0.6 line heights wide, that
+        at most ``tol`` cells reach into (one over-long cell that runs up to its neighbour must not glue two columns
+        of an eight-row table together), with cells on both sides."""
+        b = self.b
+        x0, x1 = b[idx, 0], b[idx, 2]
+        edges = np.unique(np.concatenate([x0, x1]))
+        cuts: List[float] = []
+        start = None                     # left end of the current run of sparsely covered intervals
+        for a, e in zip(edges[:-1], edges[1:]):
+            cover = int(np.count_nonzero((x0 < e) & (x1 > a)))
+            if cover <= tol:
+                if start is None:
+                    start = float(a)
+                end = float(e)
+            else:
+                if start is not None and end - start >= 0.6 * self.h_med and np.any(x1 <= start + 1e-9):
+                    cuts.append(0.5 * (start + end))
+                start = None
+        return cuts
+
     def is_table(self, idx: np.ndarray, min_rows: int) -> bool:
         """A region is a table when its boxes form a grid: at least ``min_rows`` rows of two or more cells each, the
-        cells of all rows falling into common columns (the whitespace between the columns runs through every row, at
-        least 0.6 line heights wide), no row with two cells in one column, every column filled in at least half of the
+        cells of all rows falling into common columns (the whitespace between the columns runs through every row - from
+        six rows on, through all but one - at least 0.6 line heights wide), no row with two cells in one column, every column filled in at least half of the
         rows, and at most one column of long text (two columns of running text whose lines happen to share baselines
         are not a table).  Cells that wrap onto a second line are not handled: such a region stays ordinary text."""
         b = self.b
@@ -107,7 +128,7 @@ class _Cutter:
         rows = self.rows_of(idx)
         if len(rows) < min_rows or any(r.size < 2 for r in rows):
             return False
-        cuts = sorted(0.5 * (s + e) for w, s, e in _gaps(b[idx, 0], b[idx, 2]) if w >= 0.6 * self.h_med)
+        cuts = self.table_cuts(idx, 1 if len(rows) >= 6 else 0)
         if not cuts:
             return False
         C = len(cuts) + 1
@@ -136,7 +157,7 @@ class _Cutter:
             return True
         # a column that also holds a table: the many short cells pull the median down, the long lines are still there
         longs = int(np.count_nonzero(w / h >= 8.0))
-        return longs >= self.min_col_lines and 4 * longs >= idx.size
+        return longs >= self.min_col_lines
 
     def column_cuts(self, idx: np.ndarray) -> List[float]:
         g = [x for x in _gaps(self.b[idx, 0], self.b[idx, 2]) if x[0] >= self.tx]

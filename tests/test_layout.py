@@ -271,3 +271,29 @@ def test_table_in_a_born_digital_pdf_becomes_a_table_item():
     assert "<td>Toner black</td><td>3</td><td>61.00</td><td>183.00</td>" in tabs[0]["table_body"]
     texts = [it["text"] for it in items if it["type"] == "text"]
     assert "Order 2024-117" in texts and "ACME Office Supplies" in texts
+
+
+def test_one_overlong_cell_does_not_glue_two_columns_together():
+    """Detector boxes of an eight-row table inside the left column of a two-column page, row three's first cell running
+    up to its neighbour (25 pixels apart): still one table of 8 x 3, in both implementations, and the grid keeps the
+    long cell in its own column."""
+    from distributed_llms_amd.runtime.document import table_grid
+    from distributed_llms_amd.runtime.engine import TextLine
+
+    para = [[187, 189, 1115, 253], [184, 255, 1104, 319], [182, 315, 1112, 386], [186, 387, 951, 445]]
+    cells = [[192, 515, 368, 575], [512, 515, 737, 575], [831, 515, 1050, 575], [189, 659, 441, 726], [508, 660, 712, 725],
+             [844, 669, 996, 722], [189, 808, 470, 875], [495, 808, 720, 874], [833, 812, 1004, 876], [189, 957, 447, 1023],
+             [509, 958, 686, 1022], [838, 966, 1004, 1019], [194, 1115, 338, 1168], [511, 1106, 712, 1172],
+             [828, 1110, 1027, 1170], [187, 1257, 399, 1323], [508, 1251, 687, 1321], [826, 1251, 1030, 1322],
+             [197, 1408, 406, 1468], [514, 1412, 650, 1469], [837, 1400, 1005, 1470], [192, 1559, 368, 1619],
+             [508, 1552, 710, 1618], [846, 1561, 1001, 1614]]
+    after = [[182, 1767, 1059, 1837], [187, 1836, 1089, 1900], [187, 1902, 1110, 1966]]
+    right = [[1308, 517 + 60 * k, 2200, 575 + 60 * k] for k in range(14)]
+    boxes = np.asarray(para + cells + after + right, np.float32)
+    a, b = layout.order_page(boxes, 3508.0), layout.order_page_native(boxes, 3508.0)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    order, block, kind = b
+    assert [int(i) for i, k in zip(order, kind) if k == 2] == list(range(4, 28))
+    grid = table_grid([TextLine(tuple(float(v) for v in bx), f"c{i}", 1.0, 1, 0.0, "cell") for i, bx in enumerate(cells)])
+    assert grid == [[f"c{3 * r + c}" for c in range(3)] for r in range(8)]
