@@ -96,6 +96,12 @@ class PageTruth:
     formulas: np.ndarray = field(default_factory=lambda: np.zeros((0, 4), np.float32))  # display formulas, same frame
     formula_texts: List[str] = field(default_factory=list)     # their LaTeX source
     formula_pos: List[int] = field(default_factory=list)       # number of text lines that precede each formula
+    # formulas inside text lines: span boxes (same frame), LaTeX source, index of the line in ``texts`` (whose text
+    # carries the formula as ``$...$``), and per such line its parts left to right: ("t" | "m", x0, x1, text)
+    inline: np.ndarray = field(default_factory=lambda: np.zeros((0, 4), np.float32))
+    inline_texts: List[str] = field(default_factory=list)
+    inline_line: List[int] = field(default_factory=list)
+    line_parts: dict = field(default_factory=dict)
 
     def rotated_rects(self, size: Tuple[int, int]) -> np.ndarray:
         """Line boxes in the frame of the skewed image: [n, 5] cx, cy, w, h, angle (degrees, counter-clockwise)."""
@@ -325,6 +331,41 @@ def random_formula(rng: np.random.Generator, max_tokens: int = 14) -> str:
     return body
 
 
+def random_inline_formula(rng: np.random.Generator) -> str:
+    """A short formula of the kind that sits inside a sentence: one to three atoms joined by operators, sub / superscripts,
+    Greek letters, function calls - nothing taller than a text line (no fractions, no big operators)."""
+
+    def atom() -> str:
+        r = rng.random()
+        if r < 0.45:
+            a = _F_VARS[int(rng.integers(len(_F_VARS)))]
+        elif r < 0.70:
+            a = _F_GREEK[int(rng.integers(len(_F_GREEK)))]
+        elif r < 0.82:
+            a = str(int(rng.integers(0, 100)))
+        elif r < 0.92:
+            a = "%s(%s)" % (_F_FUNCS[int(rng.integers(len(_F_FUNCS)))], _F_VARS[int(rng.integers(len(_F_VARS)))])
+        else:
+            a = "\\sqrt{%s}" % _F_VARS[int(rng.integers(len(_F_VARS)))]
+        if a[0] not in "(\\0123456789" or a.startswith(("\\alpha", "\\beta", "\\gamma", "\\lambda", "\\sigma", "\\mu")):
+            q = rng.random()
+            if q < 0.35:
+                a += "_{%s}" % (_F_VARS[int(rng.integers(len(_F_VARS)))] if rng.random() < 0.6 else str(int(rng.integers(0, 10))))
+            if 0.25 < q < 0.5:
+                a += "^{%s}" % (str(int(rng.integers(2, 5))) if rng.random() < 0.7 else _F_VARS[int(rng.integers(len(_F_VARS)))])
+        return a
+
+    n = int(rng.integers(1, 4))
+    parts = [atom()]
+    for _ in range(n - 1):
+        parts.append(_F_OPS[int(rng.integers(len(_F_OPS)))])
+        parts.append(atom())
+    body = " ".join(parts)
+    if n == 1 and len(body) <= 2:                      # a lone letter or number is not recognisable as mathematics
+        body = "%s %s %s" % (body, _F_OPS[int(rng.integers(len(_F_OPS)))], atom())
+    return body
+
+
 _MATH_PARSER = None
 _MATH_LOCK = None
 
@@ -332,6 +373,12 @@ _MATH_LOCK = None
 def render_formula(latex: str, px: int = 42, fontset: str = "cm") -> Optional[np.ndarray]:
     """LaTeX -> uint8 [h, w] coverage (0 = paper, 255 = full ink), tightly cropped, through matplotlib's mathtext.
     ``px`` is the height of an ordinary letter's em box in pixels.  None when mathtext cannot parse the string."""
+    r = render_formula_baseline(latex, px, fontset)
+    return None if r is None else r[0]
+
+
+def render_formula_baseline(latex: str, px: int = 42, fontset: str = "cm") -> Optional[Tuple[np.ndarray, int]]:
+    """As ``render_formula`` plus the row of the crop on which the text baseline lies (for setting a formula into a line)."""
     global _MATH_PARSER, _MATH_LOCK
     import threading
 
@@ -348,10 +395,11 @@ def render_formula(latex: str, px: int = 42, fontset: str = "cm") -> Optional[np
         except Exception:  # noqa: BLE001 - pyparsing errors of many kinds
             return None
         a = np.asarray(r.image, dtype=np.uint8).copy()
+        depth = float(r.depth)
     ys, xs = np.nonzero(a > 8)
     if ys.size == 0:
         return None
-    return a[ys.min() : ys.max() + 1, xs.min() : xs.max() + 1]
+    return a[ys.min() : ys.max() + 1, xs.min() : xs.max() + 1], int(round(a.shape[0] - depth)) - int(ys.min())
 
 
 LAYOUTS = ("single", "two_col", "two_col_title", "figure")
@@ -362,14 +410,16 @@ def render_layout_page(seed: int, size: Tuple[int, int] = A4_300DPI, layout: Opt
                        fonts: Optional[Sequence[str]] = None, font_px: Optional[int] = None, skew: float = 0.0,
                        noise: float = 2.0, blur: float = 0.0, margin: Optional[int] = None,
                        header_footer: Optional[bool] = None, formulas: float = 0.0,
-                       i18n: float = 0.0, script: Optional[str] = None) -> Tuple[np.ndarray, PageTruth]:
+                       i18n: float = 0.0, script: Optional[str] = None, inline: float = 0.0) -> Tuple[np.ndarray, PageTruth]:
     """A synthetic scanned page with a real layout: running header / footer, an optional full-width title, one or
     two columns of paragraphs, optionally a figure with its caption inside a column; one font per page drawn from
     ``fonts``; optional skew (degrees), blur and sensor noise.  ``formulas`` > 0: that share of the paragraph breaks
     carries a centred display formula (``random_formula`` through mathtext).  ``i18n``: probability that the page is
     written in the Western European vocabulary (accented letters, ß, œ, € ...) mixed with the English one.
     ``script``: ``"cyrillic"`` / ``"greek"`` writes the page in the Russian / Greek vocabulary of ``utils.scripts`` (one
-    word in ten stays English, as in real documents) with a font that has the alphabet.  The truth lists the lines in READING
+    word in ten stays English, as in real documents) with a font that has the alphabet.  ``inline``: that share of the
+    paragraph lines carries one or two short formulas inside the sentence (``random_inline_formula``, set on the text
+    baseline; the line's truth text holds them as ``$...$``).  The truth lists the lines in READING
     order (header, title, first column top to bottom, second column, footer) in the upright frame plus ``angle``."""
     W, H = size
     rng = np.random.default_rng(seed)
@@ -429,6 +479,70 @@ def render_layout_page(seed: int, size: Tuple[int, int] = A4_300DPI, layout: Opt
         blocks.append(block_id[0])
         return bb[3]
 
+    iboxes, itexts, iline, line_parts = [], [], [], {}
+    ascent = f.getmetrics()[0]
+    space = max(2, int(round(f.getlength("a b") - f.getlength("ab"))))
+
+    def put_inline(x: int, y: int, max_x: int, max_chars: int) -> bool:
+        """words, formula, words (, formula, words) on one baseline; False when the pieces do not fit."""
+        nf = 1 if rng.random() < 0.7 else 2
+        maths = []
+        for _ in range(nf):
+            latex = random_inline_formula(rng)
+            r = render_formula_baseline(latex, int(round(px * rng.uniform(0.95, 1.1))), fontset)
+            if r is None or r[0].shape[1] < px or r[0].shape[1] > 0.4 * (max_x - x):
+                return False
+            maths.append((latex, r[0], r[1]))
+        free = (max_x - x) - sum(m[1].shape[1] + 2 * space for m in maths)
+        budget = int(free / avg_char) - 2
+        if budget < 6 * (nf + 1):
+            return False
+        cuts = sorted(int(v) for v in rng.uniform(0.12, 0.88, size=nf) * budget)
+        shares = [cuts[0]] + [b_ - a_ for a_, b_ in zip(cuts, cuts[1:])] + [budget - cuts[-1]]
+        col = ink()
+        parts, cur = [], x
+        y_lo, y_hi = 1 << 30, -1
+        for k in range(nf + 1):
+            t = _font_safe(random_text(rng, max(3, shares[k]), min_words=1), fname).replace("$", "")
+            if k == 0 and rng.random() < 0.12:
+                t = ""                                      # the line begins with the formula
+            if k == nf and rng.random() < 0.12:
+                t = ""                                      # ... or ends with it
+            if t:
+                bb = d.textbbox((cur, y), t, font=f)
+                if bb[2] > max_x:
+                    return False
+                parts.append(("t", bb[0], bb[2], t, bb[1], bb[3]))
+                cur = bb[2] + space
+            if k < nf:
+                latex, cov, base = maths[k]
+                top = y + ascent - base
+                parts.append(("m", cur, cur + cov.shape[1], latex, top, top + cov.shape[0], cov))
+                cur += cov.shape[1] + space
+        if cur - space > max_x or not any(p_[0] == "t" for p_ in parts):
+            return False
+        for p_ in parts:
+            if p_[0] == "t":
+                d.text((p_[1], y), p_[3], fill=col, font=f)
+            else:
+                cov = p_[6].astype(np.float32) / 255.0
+                reg = np.asarray(img.crop((p_[1], p_[4], p_[2], p_[5])), dtype=np.float32)
+                img.paste(Image.fromarray((reg * (1 - cov) + col * cov).astype(np.uint8)), (p_[1], p_[4]))
+            y_lo, y_hi = min(y_lo, p_[4]), max(y_hi, p_[5])
+        ty = [p_ for p_ in parts if p_[0] == "t"]
+        t_lo, t_hi = min(p_[4] for p_ in ty), max(p_[5] for p_ in ty)
+        li = len(texts)
+        boxes.append([parts[0][1] - 3, y_lo - 3, parts[-1][2] + 3, y_hi + 3])
+        texts.append(" ".join(p_[3] if p_[0] == "t" else "$" + p_[3] + "$" for p_ in parts))
+        blocks.append(block_id[0])
+        line_parts[li] = [(p_[0], float(p_[1]), float(p_[2]), p_[3]) for p_ in parts]
+        for p_ in parts:
+            if p_[0] == "m":
+                iboxes.append([p_[1] - 2, min(t_lo, p_[4]) - 2, p_[2] + 2, max(t_hi, p_[5]) + 2])
+                itexts.append(p_[3])
+                iline.append(li)
+        return True
+
     avg_char = max(1.0, f.getlength("abcdefghij") / 10.0)
     with_hf = bool(rng.random() < 0.6) if header_footer is None else header_footer
     top, bottom = margin, H - margin
@@ -485,8 +599,9 @@ def render_layout_page(seed: int, size: Tuple[int, int] = A4_300DPI, layout: Opt
                 block_id[0] += 1
                 continue
             frac = 1.0 if rng.random() > 0.16 else float(rng.uniform(0.3, 0.8))
-            t = random_text(rng, max(6, int(max_chars * frac)), min_words=2)
-            put(x0 + (0 if rng.random() > 0.1 else int(rng.integers(1, 4) * px)), yc, t, f, x1)
+            if not (inline > 0 and frac == 1.0 and rng.random() < inline and put_inline(x0, yc, x1, max_chars)):
+                t = random_text(rng, max(6, int(max_chars * frac)), min_words=2)
+                put(x0 + (0 if rng.random() > 0.1 else int(rng.integers(1, 4) * px)), yc, t, f, x1)
             yc += line_h
             if frac < 1.0 or rng.random() < 0.05:
                 yc += int(rng.uniform(0.9, 1.4) * line_h)       # paragraph gap
@@ -521,7 +636,8 @@ def render_layout_page(seed: int, size: Tuple[int, int] = A4_300DPI, layout: Opt
         arr = np.clip(arr.astype(np.float32) + nz, 0, 255).astype(np.uint8)
     truth = PageTruth(np.asarray(boxes, dtype=np.float32).reshape(-1, 4), texts,
                       np.asarray(figures, dtype=np.float32).reshape(-1, 4), blocks, float(skew), layout, [fname],
-                      np.asarray(fboxes, dtype=np.float32).reshape(-1, 4), ftexts, fpos)
+                      np.asarray(fboxes, dtype=np.float32).reshape(-1, 4), ftexts, fpos,
+                      np.asarray(iboxes, dtype=np.float32).reshape(-1, 4), itexts, iline, line_parts)
     return arr, truth
 
 

@@ -162,12 +162,14 @@ class EngineConfig:
     fig_max_page_share: float = 0.4   # a "figure" that covers more of the page than this is a tinted page, not a figure
     fig_max_lines: int = 8            # ... and one that holds this many text lines is a text region
     detect_formulas: bool = True      # second channel of the block head -> formula boxes -> formula recogniser
+    inline_formulas: bool = True      # formula boxes inside a text line: the line is read in pieces, ``... $x_{i}$ ...``
     # a display formula is 60-100 page pixels tall = 6-10 pixels of the 1/4-scale block map: smaller size floor
     frm_db: dbpost.DBPostConfig = field(default_factory=lambda: dbpost.DBPostConfig(
-        bin_thresh=0.5, box_thresh=0.5, unclip_ratio=0.0, min_size=2, max_components=1024, max_boxes=64, max_angle_deg=0.0))
+        bin_thresh=0.5, box_thresh=0.5, unclip_ratio=0.0, min_size=1, max_components=1024, max_boxes=64, max_angle_deg=0.0))
+    # (min_size 1: the band that marks a formula inside a text line is three map pixels tall)
     formula_min_side_px: int = 16
     formula_max_tokens: int = 96
-    max_formulas_per_page: int = 32
+    max_formulas_per_page: int = 64
 
 
 class StageTimer:
@@ -210,6 +212,105 @@ def deskewed_boxes(b4: np.ndarray, angles: np.ndarray, page_hw: Tuple[int, int])
     rx, ry = cx * c - cy * s_ + 0.5 * W, cx * s_ + cy * c + 0.5 * H
     hw, hh = 0.5 * (b4[:, 2] - b4[:, 0]), 0.5 * (b4[:, 3] - b4[:, 1])
     return np.stack([rx - hw, ry - hh, rx + hw, ry + hh], 1).astype(np.float32), a
+
+
+KIND_TEXT, KIND_FORMULA, KIND_CELL, KIND_TEXT_CONT, KIND_MATH_CONT, KIND_MATH_HEAD = 0, 1, 2, 3, 4, 5
+_MATH_KINDS = (KIND_FORMULA, KIND_MATH_CONT, KIND_MATH_HEAD)
+
+
+def assign_inline_formulas(lines: np.ndarray, q: np.ndarray) -> Tuple[dict, np.ndarray]:
+    """Which formula boxes sit INSIDE a text line.  ``lines`` [n, >= 7]: x0, y0, x1, y1, score, block, angle of the line
+    rectangles (turned by ``angle`` about their centre; rows of NaN are skipped), ``q`` [m, >= 4] upright formula boxes.
+    A formula box whose centre lies in a line's rectangle, with at least one line height of that line left over beside
+    it, is part of the line (the text detector fires on the pieces of a display formula too, but those pieces end where
+    the formula ends).  -> ({line index: [(a0, a1, score)] along the line's axis relative to its centre, sorted},
+    mask over ``q``)."""
+    taken = np.zeros((q.shape[0],), bool)
+    spans: dict = {}
+    if lines.shape[0] == 0 or q.shape[0] == 0:
+        return spans, taken
+    cx, cy = 0.5 * (lines[:, 0] + lines[:, 2]), 0.5 * (lines[:, 1] + lines[:, 3])
+    w, h = lines[:, 2] - lines[:, 0], lines[:, 3] - lines[:, 1]
+    th = lines[:, 6] if lines.shape[1] > 6 else np.zeros_like(cx)
+    c, sn = np.cos(th), np.sin(th)
+    with np.errstate(invalid="ignore"):
+        for j in range(q.shape[0]):
+            qx, qy = 0.5 * (q[j, 0] + q[j, 2]), 0.5 * (q[j, 1] + q[j, 3])
+            qw, qh = q[j, 2] - q[j, 0], q[j, 3] - q[j, 1]
+            dx, dy = qx - cx, qy - cy
+            along, across = dx * c + dy * sn, -dx * sn + dy * c
+            ok = ((np.abs(along) <= 0.5 * w) & (np.abs(across) <= 0.5 * h) & (w >= qw + 1.0 * h) & (qh <= 1.3 * h) &
+                  (w >= 2.0 * h))
+            if not ok.any():
+                continue
+            i = int(np.argmin(np.where(ok, np.abs(across), np.inf)))
+            a0, a1 = max(-0.5 * w[i], along[i] - 0.5 * qw), min(0.5 * w[i], along[i] + 0.5 * qw)
+            if a1 - a0 < 4.0:
+                continue
+            taken[j] = True
+            spans.setdefault(i, []).append((float(a0), float(a1), float(q[j, 4]) if q.shape[1] > 4 else 1.0))
+    for i in spans:
+        spans[i].sort()
+    return spans, taken
+
+
+def split_line_at_formulas(row: np.ndarray, spans, min_text: float = 0.45) -> np.ndarray:
+    """One line row (x0, y0, x1, y1, score, block, angle, kind) -> its pieces left to right as rows of the same form:
+    stretches of text (kind 0 for the first piece, 3 after it) and formulas (5 / 4).  A stretch of text shorter than
+    ``min_text`` line heights is a sliver between a formula and the line's end, not text."""
+    cx, cy = 0.5 * (row[0] + row[2]), 0.5 * (row[1] + row[3])
+    w, h = row[2] - row[0], row[3] - row[1]
+    c, sn = np.cos(row[6]), np.sin(row[6])
+    parts = []
+    cur = -0.5 * w
+    for a0, a1, sc in spans:
+        a0 = max(a0, cur)
+        if a1 - a0 < 4.0:
+            continue
+        if a0 - cur >= min_text * h:
+            parts.append((cur, a0, False, row[4]))
+        parts.append((a0, a1, True, sc))
+        cur = a1
+    if 0.5 * w - cur >= min_text * h:
+        parts.append((cur, 0.5 * w, False, row[4]))
+    out = np.zeros((len(parts), row.shape[0]), np.float32)
+    for k, (u, v, is_math, sc) in enumerate(parts):
+        m, half = 0.5 * (u + v), 0.5 * (v - u)
+        px, py = cx + m * c, cy + m * sn
+        out[k] = row
+        out[k, :5] = (px - half, py - 0.5 * h, px + half, py + 0.5 * h, sc)
+        if is_math:
+            out[k, 7] = KIND_MATH_HEAD if k == 0 else KIND_MATH_CONT
+        else:
+            out[k, 7] = KIND_TEXT if k == 0 else KIND_TEXT_CONT
+    return out
+
+
+def widest_gap(profile: np.ndarray, centre: int, min_run: int = 3) -> Optional[int]:
+    """Column of the middle of the widest run of paper in ``profile`` (darkest sample per pixel column, 0 = ink),
+    ``centre`` breaking ties towards the estimate.  None when no run of ``min_run`` columns is blank."""
+    if profile.size == 0:
+        return None
+    lo, hi = float(profile.min()), float(profile.max())
+    if hi - lo < 24.0:                      # nothing but paper (or nothing but ink): keep the estimate
+        return None
+    blank = profile >= hi - 0.3 * (hi - lo)
+    best, best_key = None, None
+    k, n = 0, blank.size
+    while k < n:
+        if not blank[k]:
+            k += 1
+            continue
+        e = k
+        while e < n and blank[e]:
+            e += 1
+        if e - k >= min_run:
+            mid = (k + e - 1) // 2
+            key = (e - k) - 0.35 * abs(mid - centre)
+            if best is None or key > best_key:
+                best, best_key = mid, key
+        k = e
+    return best
 
 
 def balanced_chunks(n: int, limit: int) -> List[Tuple[int, int]]:
@@ -456,9 +557,15 @@ class OcrEngine:
             if r.shape[1] < 8:
                 r = np.concatenate([r, np.zeros((r.shape[0], 8 - r.shape[1]), np.float32)], 1)
             r[:, 7] = 0.0
+            inline_q = None
             if frms is not None and frms[pi].shape[0]:
                 q = frms[pi]
                 q = q[np.minimum(q[:, 2] - q[:, 0], q[:, 3] - q[:, 1]) >= cfg.formula_min_side_px][: cfg.max_formulas_per_page]
+                if q.shape[0] and cfg.inline_formulas:
+                    # formulas inside a text line are set aside here and cut out of their line after the layout analysis
+                    _, in_line = assign_inline_formulas(r, q)
+                    inline_q = q[in_line]
+                    q = q[~in_line]
                 if q.shape[0]:
                     # the text detector also fires on the pieces of a formula: what lies inside a formula box is dropped
                     cx, cy = 0.5 * (r[:, 0] + r[:, 2]), 0.5 * (r[:, 1] + r[:, 3])
@@ -530,8 +637,53 @@ class OcrEngine:
                                     knd[:, None]], 1)
             pos = np.nonzero(~is_line)[0]
             fo = np.concatenate([fg[order[pos] - n], pos[:, None].astype(np.float32)], 1) if pos.size else np.zeros((0, 5), np.float32)
+            if inline_q is not None and inline_q.shape[0]:
+                # (the pieces of a line become one line again in ``_finish``: figure positions stay as they are)
+                spans, _ = assign_inline_formulas(np.where(lines[:, 7:8] == KIND_TEXT, lines, np.nan), inline_q)
+                if spans and self.on_gpu and pi < len(db.srcs):
+                    spans = self._refine_spans(db.srcs[pi], lines, spans)
+                if spans:
+                    lines = np.concatenate([split_line_at_formulas(lines[k], spans[k]) if k in spans else lines[k : k + 1]
+                                            for k in range(lines.shape[0])], 0)
             out.append((lines.astype(np.float32), fo.astype(np.float32)))
         return out
+
+    def _refine_spans(self, src: torch.Tensor, lines: np.ndarray, spans: dict) -> dict:
+        """The formula map has a quarter of the detector's resolution: +-10 page pixels at the ends of a formula, a third
+        of a letter.  Move every end to the middle of the widest gap between glyphs near it (the word space), read from
+        the page pixels: the darkest sample of each pixel column over the middle of the line."""
+        H, W = int(src.shape[0]), int(src.shape[1])
+        L = 96
+        jobs, profs = [], []
+        for k, sp in spans.items():
+            cx, cy = 0.5 * (lines[k, 0] + lines[k, 2]), 0.5 * (lines[k, 1] + lines[k, 3])
+            w, h = lines[k, 2] - lines[k, 0], lines[k, 3] - lines[k, 1]
+            c, sn = float(np.cos(lines[k, 6])), float(np.sin(lines[k, 6]))
+            reach = int(min(L // 2 - 1, max(8.0, 0.55 * h)))
+            for j, (a0, a1, _) in enumerate(sp):
+                for end, a in ((0, a0), (1, a1)):
+                    if abs(abs(a) - 0.5 * w) < 2.0:          # the formula ends where the line ends
+                        continue
+                    bx, by = int(round(cx + a * c)), int(round(cy + a * sn))
+                    x0, x1 = max(0, bx - reach), min(W, bx + reach + 1)
+                    y0, y1 = max(0, int(by - 0.28 * h)), min(H, int(by + 0.28 * h) + 1)
+                    if x1 - x0 < 8 or y1 - y0 < 2:
+                        continue
+                    strip = src[y0:y1, x0:x1]
+                    if strip.dim() == 3:
+                        strip = strip[..., 0]
+                    pr = strip.amin(0)
+                    profs.append(torch.nn.functional.pad(pr, (0, L - pr.shape[0])))
+                    jobs.append((k, j, end, x0 - bx, int(pr.shape[0])))
+        if not jobs:
+            return spans
+        host = torch.stack(profs).cpu().numpy()
+        out = {k: [list(t) for t in sp] for k, sp in spans.items()}
+        for row, (k, j, end, off, n) in zip(host, jobs):
+            g = widest_gap(row[:n], -off)
+            if g is not None:
+                out[k][j][end] += float(g + off)              # along the (nearly level) line: one column = one pixel
+        return {k: [tuple(t) for t in sp if t[1] - t[0] >= 4.0] for k, sp in out.items()}
 
     # ------------------------------------------------------------------ recognition stage
     def _plan_crops(self, db: _DetBatch, det_boxes):
@@ -564,7 +716,7 @@ class OcrEngine:
         kind = np.concatenate([pp[5] for pp in per_page], 0) if per_page else np.zeros((0,), np.int32)
         w = boxes[:, 2] - boxes[:, 0]
         h = boxes[:, 3] - boxes[:, 1]
-        ok = (w >= cfg.min_line_px) & (h >= cfg.min_line_px) & (kind != 1)
+        ok = (w >= cfg.min_line_px) & (h >= cfg.min_line_px) & ~np.isin(kind, _MATH_KINDS)
         rot = (h > cfg.vertical_ratio * w).astype(np.int32)
         long_side = np.where(rot == 1, h, w)
         short_side = np.maximum(np.where(rot == 1, w, h), 1.0)
@@ -684,7 +836,7 @@ class OcrEngine:
         """Formula boxes of the batch -> letter-boxed 96 x 384 crops -> encoder-decoder -> LaTeX token ids (started
         here, read in ``_finish``).  Returns (global line indices, tokens, confidences) or None."""
         kind = np.concatenate([pp[5] for pp in per_page], 0) if per_page else np.zeros((0,), np.int32)
-        idx = np.nonzero(kind == 1)[0]
+        idx = np.nonzero(np.isin(kind, _MATH_KINDS))[0]
         if idx.size == 0 or self.formula_rec is None:
             return None
         from ..models.trocr import FORMULA_HW
@@ -868,14 +1020,31 @@ class OcrEngine:
         for pi, (p, (n_det, used_prior, b4, blk, fg, knd)) in enumerate(zip(rb.det.pages, per_page)):
             r = PageResult(p.doc_id, p.page_index, p.hw[1], p.hw[0],
                            n_detected=n_det, used_layout_prior=used_prior, error=rb.det.page_errors.get(pi))
+            cur = None                  # the line whose pieces (text, formula, text, ...) are being put together
             for k in range(b4.shape[0]):
                 gi = pos + k
-                if knd[k] == 1:
+                if knd[k] == KIND_FORMULA:
+                    cur = None
                     r.lines.append(TextLine(tuple(float(v) for v in b4[k, :4]), texts[gi], float(confs[gi]), int(blk[k]),
                                             0.0, "equation"))
-                elif ok[gi]:
-                    r.lines.append(TextLine(tuple(float(v) for v in b4[k, :4]), texts[gi], float(confs[gi]), int(blk[k]),
-                                            float(b4[k, 4]), "cell" if knd[k] == 2 else "text"))
+                    continue
+                math = knd[k] in (KIND_MATH_CONT, KIND_MATH_HEAD)
+                if not (math or ok[gi]):
+                    if knd[k] not in (KIND_TEXT_CONT, KIND_MATH_CONT):
+                        cur = None
+                    continue
+                piece = ("$" + texts[gi].strip() + "$" if texts[gi].strip() else "") if math else texts[gi]
+                if knd[k] in (KIND_TEXT_CONT, KIND_MATH_CONT) and cur is not None:
+                    if piece:
+                        cur.text = (cur.text + " " + piece).strip()
+                    bb = b4[k, :4]
+                    cur.box = (min(cur.box[0], float(bb[0])), min(cur.box[1], float(bb[1])),
+                               max(cur.box[2], float(bb[2])), max(cur.box[3], float(bb[3])))
+                    cur.confidence = min(cur.confidence, float(confs[gi]))
+                    continue
+                cur = TextLine(tuple(float(v) for v in b4[k, :4]), piece, float(confs[gi]), int(blk[k]),
+                               float(b4[k, 4]), "cell" if knd[k] == KIND_CELL else "text")
+                r.lines.append(cur)
             for k in range(fg.shape[0]):
                 crop = rb.fig_crops.get((pi, k))
                 if crop is not None:

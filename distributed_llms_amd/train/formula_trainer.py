@@ -33,17 +33,28 @@ from .trainer import _edit_distance
 from .trocr_trainer import Seq2SeqConfig, Seq2SeqTrainer
 
 
-def formula_sample(seed: int) -> Tuple[np.ndarray, str]:
-    """One training crop (uint8 gray, variable size) and its LaTeX."""
+def formula_sample(seed: int, inline_share: float = 0.0) -> Tuple[np.ndarray, str]:
+    """One training crop (uint8 gray, variable size) and its LaTeX.  ``inline_share`` of the crops are short formulas as
+    they are cut out of a text line: the line's full height around them, the cut somewhere in the word spaces."""
     rng = np.random.default_rng(seed)
+    inline = inline_share > 0 and rng.random() < inline_share
     for _ in range(8):
-        latex = synth.random_formula(rng)
-        cov = synth.render_formula(latex, int(rng.integers(30, 64)), synth.FORMULA_FONTSETS[int(rng.integers(5))])
-        if cov is not None and cov.shape[1] >= 12:
+        latex = synth.random_inline_formula(rng) if inline else synth.random_formula(rng)
+        px = int(rng.integers(28, 52)) if inline else int(rng.integers(30, 64))
+        r = synth.render_formula_baseline(latex, px, synth.FORMULA_FONTSETS[int(rng.integers(5))])
+        if r is not None and r[0].shape[1] >= 12:
+            cov, base = r
             break
     else:
-        latex, cov = "x", synth.render_formula("x", 40)
+        latex, (cov, base) = "x", synth.render_formula_baseline("x", 40)
+        px, inline = 40, False
     pad = [int(rng.integers(2, 14)) for _ in range(4)]            # detector boxes are loose by a few pixels
+    if inline:
+        # the crop is as tall as the line's box: ascender height above the baseline, descender depth below, plus the
+        # detector's slack; left and right it ends inside a word space
+        top = int(px * rng.uniform(0.85, 1.15)) + int(rng.integers(0, 14))
+        bot = int(px * rng.uniform(0.25, 0.45)) + int(rng.integers(0, 14))
+        pad = [max(2, top - base), max(2, bot - (cov.shape[0] - base)), int(rng.integers(1, 12)), int(rng.integers(1, 12))]
     h, w = cov.shape
     paper, ink = float(rng.integers(215, 253)), float(rng.integers(5, 90))
     img = np.full((h + pad[0] + pad[1], w + pad[2] + pad[3]), paper, np.float32)
@@ -69,8 +80,9 @@ def formula_sample(seed: int) -> Tuple[np.ndarray, str]:
 
 
 def _render_chunk(args) -> List[Tuple[np.ndarray, str]]:
-    seed0, n = args
-    return [formula_sample(seed0 + k) for k in range(n)]
+    seed0, n = args[:2]
+    share = args[2] if len(args) > 2 else 0.0
+    return [formula_sample(seed0 + k, share) for k in range(n)]
 
 
 def letterbox_regions(imgs: List[torch.Tensor]) -> List[rs.Region]:
@@ -86,16 +98,18 @@ def letterbox_regions(imgs: List[torch.Tensor]) -> List[rs.Region]:
 
 
 class FormulaTrainer(Seq2SeqTrainer):
-    def __init__(self, model: TrOCR, cfg: Seq2SeqConfig, device, workers: int = 12, seed0: int = 1_000_000):
+    def __init__(self, model: TrOCR, cfg: Seq2SeqConfig, device, workers: int = 12, seed0: int = 1_000_000,
+                 inline_share: float = 0.0):
         super().__init__(model, cfg, device)
         self.seed0 = seed0
+        self.inline_share = inline_share
         self.pool = mp.get_context("spawn").Pool(workers) if workers > 0 else None
         self.pending = []
         self.per_task = 16
 
     def _submit(self, step: int):
         n = self.cfg.batch_size
-        tasks = [(self.seed0 + step * n + k, min(self.per_task, n - k)) for k in range(0, n, self.per_task)]
+        tasks = [(self.seed0 + step * n + k, min(self.per_task, n - k), self.inline_share) for k in range(0, n, self.per_task)]
         if self.pool is None:
             return [_render_chunk(t) for t in tasks]
         return self.pool.map_async(_render_chunk, tasks)
@@ -125,9 +139,9 @@ class FormulaTrainer(Seq2SeqTrainer):
         return x, torch.from_numpy(tok).to(self.device), texts
 
     @torch.no_grad()
-    def evaluate_formulas(self, n: int = 256, seed0: int = 9_000_000, through_kernels: bool = True):
+    def evaluate_formulas(self, n: int = 256, seed0: int = 9_000_000, through_kernels: bool = True, inline_share: float = 0.0):
         self.model.eval()
-        samples = _render_chunk((seed0, n))
+        samples = _render_chunk((seed0, n, inline_share))
         ok = ed = nch = 0
         for k in range(0, n, 128):
             x, _, texts = self._tensors(samples[k : k + 128])
@@ -170,6 +184,8 @@ def main(argv=None) -> int:
     ap.add_argument("--time-limit", type=float, default=900.0)
     ap.add_argument("--workers", type=int, default=12)
     ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--inline-share", type=float, default=0.0,
+                    help="share of the training crops that are short formulas cut out of a text line")
     args = ap.parse_args(argv)
     device = torch.device("cuda:0" if torch.cuda.is_available() and not args.cpu else "cpu")
     torch.manual_seed(0)
@@ -186,7 +202,7 @@ def main(argv=None) -> int:
         print(f"resumed {path} at step {start}", flush=True)
     cfg = Seq2SeqConfig(batch_size=args.batch, lr=args.lr, warmup_steps=200 if start == 0 else 20, decay_steps=args.steps,
                         max_grad_norm=1.0, weight_decay=0.01)
-    tr = FormulaTrainer(model, cfg, device, workers=args.workers)
+    tr = FormulaTrainer(model, cfg, device, workers=args.workers, inline_share=args.inline_share)
     tr.step = start
     t0 = time.perf_counter()
     ev = {}
@@ -200,6 +216,8 @@ def main(argv=None) -> int:
                 ev = tr.evaluate_formulas(128)
                 print(json.dumps({"step": tr.step, "eval": ev}), flush=True)
         ev = tr.evaluate_formulas(512)
+        if args.inline_share > 0:
+            ev["inline"] = tr.evaluate_formulas(512, seed0=9_500_000, inline_share=1.0)
     finally:
         tr.close()
     save_bf16(model, path)

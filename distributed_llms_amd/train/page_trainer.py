@@ -59,7 +59,8 @@ def augment_scan(pg: np.ndarray, rng: np.random.Generator) -> np.ndarray:
 
 
 def render_training_page(seed: int, fonts=None, plain_share: float = 0.2, max_skew: float = 5.0, formula_share: float = 0.4,
-                         i18n_share: float = 0.35, script_share: float = 0.0, table_share: float = 0.0):
+                         i18n_share: float = 0.35, script_share: float = 0.0, table_share: float = 0.0,
+                         inline_share: float = 0.0):
     """One page of the training distribution (see the module docstring) and its truth.  ``i18n_share`` of the layout
     pages are written in the Western European vocabulary (accented letters, sharp s, ligatures, currency signs);
     ``script_share`` of them in Russian or Greek (half each, ``utils.scripts``)."""
@@ -85,7 +86,9 @@ def render_training_page(seed: int, fonts=None, plain_share: float = 0.2, max_sk
     pg, truth = synth.render_layout_page(seed, fonts=fonts or synth.TRAIN_FONTS, skew=skew, blur=blur,
                                          noise=float(rng.uniform(0.5, 5.0)),
                                          formulas=float(rng.uniform(0.3, 0.9)) if rng.random() < formula_share else 0.0,
-                                         i18n=i18n_share)
+                                         i18n=i18n_share,
+                                         inline=float(rng.uniform(0.1, 0.5)) if inline_share > 0 and
+                                         np.random.default_rng(seed ^ 0x1F0A).random() < inline_share else 0.0)
     return augment_scan(pg, rng), truth
 
 
@@ -93,8 +96,9 @@ class PageProducer:
     """Renders pages on host threads and keeps a bounded queue of (uint8 page tensor on device, truth)."""
 
     def __init__(self, device, threads: int = 6, depth: int = 24, seed0: int = 100_000, fonts=None,
-                 script_share: float = 0.0, table_share: float = 0.0):
+                 script_share: float = 0.0, table_share: float = 0.0, inline_share: float = 0.0):
         self.device = device
+        self.inline_share = inline_share
         self.fonts = fonts
         self.script_share = script_share
         self.table_share = table_share
@@ -111,7 +115,8 @@ class PageProducer:
             with self._lock:
                 self._seed += 1
                 seed = self._seed
-            pg, truth = render_training_page(seed, self.fonts, script_share=self.script_share, table_share=self.table_share)
+            pg, truth = render_training_page(seed, self.fonts, script_share=self.script_share, table_share=self.table_share,
+                                             inline_share=self.inline_share)
             while not self._stop.is_set():
                 try:
                     self.q.put((torch.from_numpy(pg), truth), timeout=1.0)
@@ -185,7 +190,16 @@ def det_targets(truth: synth.PageTruth, hw: Tuple[int, int], scale: float, Hd: i
         r[:, :4] *= scale
     text = _raster_polys(rect_corners(r), Wd, Hd) if r.shape[0] else np.zeros((Hd, Wd), np.uint8)
     fig = np.zeros((2, Hd // 4, Wd // 4), np.uint8)
-    for k, bx in enumerate((truth.figures, truth.formulas)):
+    frm = truth.formulas
+    if getattr(truth, "inline", np.zeros((0, 4))).shape[0]:
+        # a formula inside a line is marked over its width and the middle 70 % of the line's height: bands of
+        # neighbouring lines stay apart on the quarter-scale map, the engine takes the height from the text line
+        q = truth.inline.astype(np.float32).copy()
+        hq = q[:, 3] - q[:, 1]
+        q[:, 1] += 0.15 * hq
+        q[:, 3] -= 0.15 * hq
+        frm = np.concatenate([frm.reshape(-1, 4), q], 0)
+    for k, bx in enumerate((truth.figures, frm)):
         if bx.shape[0]:
             f = synth.rotate_boxes(bx, truth.angle, (hw[1], hw[0])).astype(np.float64)
             f[:, 4] = -np.deg2rad(f[:, 4])
@@ -249,7 +263,24 @@ def rec_batch(pages, model: CRNN, device, max_lines=64, jitter=0.12, angle_jitte
     for img, truth in pages:
         H, W = img.shape
         rects = line_rects(truth, (H, W))
-        for r, t in zip(rects, truth.texts):
+        items = []
+        parts_of = getattr(truth, "line_parts", None) or {}
+        for li, (r, t) in enumerate(zip(rects, truth.texts)):
+            if li not in parts_of:
+                items.append((r, t))
+                continue
+            # a line with formulas inside: the recogniser reads the stretches of text between them, cut somewhere in the
+            # word space next to the formula (the engine cuts there too)
+            bx = truth.boxes[li]
+            sp = 0.12 * r[3]
+            for kind, xa, xb, txt in parts_of[li]:
+                if kind != "t":
+                    continue
+                xa = max(float(bx[0]), xa - np.random.uniform(0.0, 2.0) * sp)
+                xb = min(float(bx[2]), xb + np.random.uniform(0.0, 2.0) * sp)
+                m = 0.5 * (xa + xb) - 0.5 * float(bx[0] + bx[2])
+                items.append((np.array([r[0] + m * np.cos(r[4]), r[1] + m * np.sin(r[4]), xb - xa, r[3], r[4]]), txt))
+        for r, t in items:
             # detector boxes are not pixel-exact: jitter every side by a fraction of the line height, and the angle
             # by what the second-moment estimate is off on a short line
             j = np.random.uniform(-jitter, jitter, size=4) * r[3]
@@ -332,6 +363,10 @@ def evaluate_pages(engine, pages_truth, verbose=False):
     n_truth = n_found = ed = nchar = ed_page = 0
     fig_truth = fig_found = 0
     frm_truth = frm_found = frm_ed = frm_ch = frm_false = 0
+    inl_truth = inl_found = inl_ed = inl_ch = inl_false = 0
+    import re
+
+    spans_of = lambda text: re.findall(r"\$([^$]*)\$", text)      # noqa: E731
     for r, (pg, tr) in zip(res, pages_truth):
         rects = line_rects(tr, pg.shape)
         eqs = [l for l in r.lines if getattr(l, "kind", "text") == "equation"]
@@ -368,8 +403,17 @@ def evaluate_pages(engine, pages_truth, verbose=False):
                 used.add(k)
                 n_found += 1
                 ed += _edit_distance(r.lines[k].text, t)
+                want, got = spans_of(t), spans_of(r.lines[k].text)
+                inl_truth += len(want)
+                inl_found += min(len(want), len(got))
+                inl_false += max(0, len(got) - len(want))
+                if len(want) == len(got):
+                    for a_, b_ in zip(want, got):
+                        inl_ed += min(len(a_), _edit_distance(b_.strip(), a_))
+                        inl_ch += len(a_)
             else:
                 ed += len(t)
+                inl_truth += len(spans_of(t))
         ed_page += _edit_distance("\n".join(l.text for l in r.lines), "\n".join(tr.texts))
         fig_truth += tr.figures.shape[0]
         fig_found += min(len(r.figures), tr.figures.shape[0])
@@ -380,7 +424,9 @@ def evaluate_pages(engine, pages_truth, verbose=False):
             "truth_per_page": float(np.mean([len(t.texts) for _, t in pages_truth])),
             "figures_found": fig_found, "figures_truth": fig_truth,
             "formulas_found": frm_found, "formulas_truth": frm_truth, "formulas_false": frm_false,
-            "formula_cer": frm_ed / max(frm_ch, 1)}
+            "formula_cer": frm_ed / max(frm_ch, 1),
+            "inline_found": inl_found, "inline_truth": inl_truth, "inline_false": inl_false,
+            "inline_cer": inl_ed / max(inl_ch, 1)}
 
 
 def held_out_pages(seeds, skew=3.0, fonts=None):
@@ -424,6 +470,10 @@ def evaluate(det, rec, device, seeds, verbose=False, formula_weights=None):
     out["formula_pages"] = evaluate_pages(eng, [synth.render_layout_page(sd, fonts=synth.TRAIN_FONTS, formulas=0.8,
                                                                          layout=synth.LAYOUTS[k % 3])
                                                 for k, sd in enumerate(seeds[:4])], verbose)
+    out["inline_formula_pages"] = evaluate_pages(eng, [synth.render_layout_page(sd, fonts=synth.TRAIN_FONTS, inline=0.35,
+                                                                                layout=synth.LAYOUTS[k % 3],
+                                                                                skew=1.5 * (k % 3 - 1))
+                                                       for k, sd in enumerate(seeds[:6])], verbose)
     det.train()
     rec.train()
     return out
@@ -438,6 +488,7 @@ def write_meta(out_dir: str, steps: int, ev, log, charset: str = "", history: st
                                 "contrast": [0.7, 1.15], "jpeg_quality": [35, 95], "font_px": [30, 50],
                                 "layouts": list(synth.LAYOUTS) + ["plain"],
                                 "display_formulas": "40 % of the layout pages carry formulas (synth.random_formula, mathtext)",
+                                "inline_formulas": "synth.random_inline_formula inside paragraph lines (--inline-share)",
                                 "western_european_pages": "35 % of the layout pages (synth._WORDS_I18N)",
                                 "script_train_fonts": synth.available_fonts(synth.SCRIPT_TRAIN_FONTS),
                                 "script_held_out_fonts": synth.available_fonts(synth.SCRIPT_HELD_OUT_FONTS)}},
@@ -459,6 +510,8 @@ def main(argv=None) -> int:
                     help="multi: Latin + Cyrillic + Greek shape classes (utils/scripts.py)")
     ap.add_argument("--script-share", type=float, default=0.0, help="share of the layout pages written in Russian / Greek")
     ap.add_argument("--table-share", type=float, default=0.0, help="share of the pages that carry a (ruled or unruled) table")
+    ap.add_argument("--inline-share", type=float, default=0.0,
+                    help="share of the layout pages whose paragraphs carry formulas inside the lines")
     ap.add_argument("--rec-only", action="store_true", help="leave the detector as it is: recogniser steps only")
     ap.add_argument("--lines", type=int, default=64, help="line crops per recogniser step")
     ap.add_argument("--history", default="", help="free text recorded in train_meta.json")
@@ -500,7 +553,8 @@ def main(argv=None) -> int:
     rec.own_conv_train = device.type == "cuda" and not args.library_convs
     dopt, ropt = _Opt(det, args.det_lr), _Opt(rec, args.rec_lr)
     it = start
-    prod = PageProducer(device, threads=args.threads, script_share=args.script_share, table_share=args.table_share)
+    prod = PageProducer(device, threads=args.threads, script_share=args.script_share, table_share=args.table_share,
+                        inline_share=args.inline_share)
     t0 = time.perf_counter()
     alive = threading.Event()
 

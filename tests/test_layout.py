@@ -120,7 +120,14 @@ class _PaintedDetector(torch.nn.Module):
             x0, y0, x1, y1 = [int(round(float(v))) for v in b]
             prob[:, (y0 + y1) // 2 - 2:(y0 + y1) // 2 + 2, x0 + 4:x1 - 4] = 0.9
         fig = torch.full((B, H // 4, W // 4, 8), -6.0)
-        for k, boxes in enumerate((self.truth.figures, self.truth.formulas)):
+        frm = self.truth.formulas
+        if self.truth.inline.shape[0]:                # formulas inside lines: the band the trainer paints
+            q = self.truth.inline.copy()
+            hq = q[:, 3] - q[:, 1]
+            q[:, 1] += 0.15 * hq
+            q[:, 3] -= 0.15 * hq
+            frm = np.concatenate([frm.reshape(-1, 4), q], 0)
+        for k, boxes in enumerate((self.truth.figures, frm)):
             for b in boxes * sc / 4:
                 x0, y0, x1, y1 = [int(round(float(v))) for v in b]
                 fig[:, y0:y1, x0:x1, k] = 6.0
@@ -297,3 +304,65 @@ def test_one_overlong_cell_does_not_glue_two_columns_together():
     assert [int(i) for i, k in zip(order, kind) if k == 2] == list(range(4, 28))
     grid = table_grid([TextLine(tuple(float(v) for v in bx), f"c{i}", 1.0, 1, 0.0, "cell") for i, bx in enumerate(cells)])
     assert grid == [[f"c{3 * r + c}" for c in range(3)] for r in range(8)]
+
+
+def test_formulas_inside_lines_are_cut_out_and_put_back_in_place():
+    """A page whose paragraphs carry formulas inside the lines: every such line comes back as ONE text line whose text
+    holds the formulas as $...$ between the stretches of text, in order; display formulas stay equations."""
+    from distributed_llms_amd.models.crnn import CRNN
+    from distributed_llms_amd.models.trocr import TrOCR, TrOCRConfig
+    from distributed_llms_amd.runtime import engine as E
+
+    pg, tr = synth.render_layout_page(21, size=(1240, 1754), layout="single", formulas=0.5, inline=0.5, noise=1.0)
+    assert tr.inline.shape[0] >= 4 and len(tr.line_parts) >= 3
+    torch.manual_seed(0)
+    frm = TrOCR(TrOCRConfig(image_size=192, enc_dim=64, enc_layers=1, enc_heads=1, enc_mlp=128, dec_dim=64, dec_layers=1,
+                            dec_heads=1, dec_ffn=128, vocab=272, max_len=24))
+    eng = E.OcrEngine("cpu", _PaintedDetector(tr, pg.shape), CRNN(hidden=64, widths=(16, 32, 32, 32, 64, 64)),
+                      E.EngineConfig(det_limit_side=1344, max_batch_pages=1, formula_max_tokens=12, formula_min_side_px=4),
+                      formula_rec=frm)
+    eng._strings = lambda ids, lens: ["T"] * ids.shape[0]
+    frm.tokens_to_text = lambda toks, *a: ["M"] * len(toks)
+    res = eng.process_pages([E.PageImage(torch.from_numpy(pg.copy()), "f", 0)])[0]
+    text_lines = [l for l in res.lines if l.kind == "text"]
+    assert len(text_lines) == len(tr.texts)
+    assert sum(l.kind == "equation" for l in res.lines) == tr.formulas.shape[0]
+    for li, (l, t) in enumerate(zip(text_lines, tr.texts)):
+        if li in tr.line_parts:
+            want = " ".join("T" if k == "t" else "$M$" for k, *_ in tr.line_parts[li])
+            assert l.text == want, (li, l.text, want, t)
+            tb = tr.boxes[li]
+            assert abs(l.box[0] - tb[0]) < 12 and abs(l.box[2] - tb[2]) < 12
+        else:
+            assert l.text == "T"
+
+
+def test_inline_assignment_and_split_follow_a_skewed_line():
+    from distributed_llms_amd.runtime import engine as E
+
+    th = np.deg2rad(3.0)
+    line = np.array([[100, 500, 1900, 560, 0.9, 0, th, 0]], np.float32)         # centre (1000, 530), turned 3 degrees
+    a = 600.0                                                                     # a formula 600 px right of the centre
+    q = np.array([[1000 + a * np.cos(th) - 80, 530 + a * np.sin(th) - 15, 1000 + a * np.cos(th) + 80, 530 + a * np.sin(th) + 15, 0.8],
+                  [300, 900, 900, 1000, 0.9]], np.float32)                        # and a display formula elsewhere
+    spans, taken = E.assign_inline_formulas(line, q)
+    assert taken.tolist() == [True, False] and abs(spans[0][0][0] - 520) < 1 and abs(spans[0][0][1] - 680) < 1
+    parts = E.split_line_at_formulas(line[0], spans[0])
+    assert parts[:, 7].tolist() == [E.KIND_TEXT, E.KIND_MATH_CONT, E.KIND_TEXT_CONT]
+    mid = 0.5 * (parts[1, :2] + parts[1, 2:4])
+    assert np.allclose(mid, [1000 + a * np.cos(th), 530 + a * np.sin(th)], atol=0.5)
+    assert np.allclose(parts[:, 3] - parts[:, 1], 60) and abs((parts[:, 2] - parts[:, 0]).sum() - 1800) < 1e-3
+    # a line that begins with the formula; a sliver of text at the end is dropped
+    parts = E.split_line_at_formulas(line[0], [(-900.0, -700.0, 0.7), (700.0, 885.0, 0.6)])
+    assert parts[:, 7].tolist() == [E.KIND_MATH_HEAD, E.KIND_TEXT_CONT, E.KIND_MATH_CONT]
+
+
+def test_widest_gap_picks_the_word_space_not_a_letter_gap():
+    from distributed_llms_amd.runtime.engine import widest_gap
+
+    prof = np.full(60, 240, np.uint8)
+    prof[0:10] = 30; prof[12:22] = 40          # letters with a 2-pixel gap
+    prof[34:50] = 35                           # next glyph after a 12-pixel space
+    prof[52:60] = 30
+    assert widest_gap(prof, 30) in (27, 28)
+    assert widest_gap(np.full(40, 240, np.uint8), 20) is None
