@@ -87,6 +87,7 @@ class TextLine:
     angle: float = 0.0           # radians the line is turned about the centre of ``box`` (skewed scans), 0 = upright
     kind: str = "text"           # "equation": a display formula, ``text`` is its LaTeX source; "cell": a cell of a
                                  # table (the cells of one table share ``block`` and come row by row)
+    formula_confidence: float = 1.0     # lowest mean token probability among the formulas inside the line ($...$)
 
 
 @dataclass
@@ -163,6 +164,8 @@ class EngineConfig:
     fig_max_lines: int = 8            # ... and one that holds this many text lines is a text region
     detect_formulas: bool = True      # second channel of the block head -> formula boxes -> formula recogniser
     inline_formulas: bool = True      # formula boxes inside a text line: the line is read in pieces, ``... $x_{i}$ ...``
+    inline_min_score: float = 0.5     # mean probability of the formula map over the box, below which it cuts nothing
+    inline_min_conf: float = 0.0      # mean token probability of a formula in a line, below which the line is read whole
     # a display formula is 60-100 page pixels tall = 6-10 pixels of the 1/4-scale block map: smaller size floor
     frm_db: dbpost.DBPostConfig = field(default_factory=lambda: dbpost.DBPostConfig(
         bin_thresh=0.5, box_thresh=0.5, unclip_ratio=0.0, min_size=1, max_components=1024, max_boxes=64, max_angle_deg=0.0))
@@ -214,17 +217,18 @@ def deskewed_boxes(b4: np.ndarray, angles: np.ndarray, page_hw: Tuple[int, int])
     return np.stack([rx - hw, ry - hh, rx + hw, ry + hh], 1).astype(np.float32), a
 
 
-KIND_TEXT, KIND_FORMULA, KIND_CELL, KIND_TEXT_CONT, KIND_MATH_CONT, KIND_MATH_HEAD = 0, 1, 2, 3, 4, 5
+KIND_TEXT, KIND_FORMULA, KIND_CELL, KIND_TEXT_CONT, KIND_MATH_CONT, KIND_MATH_HEAD, KIND_LINE_ALT = 0, 1, 2, 3, 4, 5, 6
 _MATH_KINDS = (KIND_FORMULA, KIND_MATH_CONT, KIND_MATH_HEAD)
 
 
-def assign_inline_formulas(lines: np.ndarray, q: np.ndarray) -> Tuple[dict, np.ndarray]:
+def assign_inline_formulas(lines: np.ndarray, q: np.ndarray, min_score: float = 0.0) -> Tuple[dict, np.ndarray]:
     """Which formula boxes sit INSIDE a text line.  ``lines`` [n, >= 7]: x0, y0, x1, y1, score, block, angle of the line
     rectangles (turned by ``angle`` about their centre; rows of NaN are skipped), ``q`` [m, >= 4] upright formula boxes.
     A formula box whose centre lies in a line's rectangle, with at least one line height of that line left over beside
     it, is part of the line (the text detector fires on the pieces of a display formula too, but those pieces end where
-    the formula ends).  -> ({line index: [(a0, a1, score)] along the line's axis relative to its centre, sorted},
-    mask over ``q``)."""
+    the formula ends).  A box inside a line whose mean probability is below ``min_score`` is set aside too (it is no
+    display formula) but cuts nothing out of its line.  -> ({line index: [(a0, a1, score)] along the line's axis
+    relative to its centre, sorted}, mask over ``q``)."""
     taken = np.zeros((q.shape[0],), bool)
     spans: dict = {}
     if lines.shape[0] == 0 or q.shape[0] == 0:
@@ -248,6 +252,8 @@ def assign_inline_formulas(lines: np.ndarray, q: np.ndarray) -> Tuple[dict, np.n
             if a1 - a0 < 4.0:
                 continue
             taken[j] = True
+            if q.shape[1] > 4 and q[j, 4] < min_score:
+                continue
             spans.setdefault(i, []).append((float(a0), float(a1), float(q[j, 4]) if q.shape[1] > 4 else 1.0))
     for i in spans:
         spans[i].sort()
@@ -257,7 +263,9 @@ def assign_inline_formulas(lines: np.ndarray, q: np.ndarray) -> Tuple[dict, np.n
 def split_line_at_formulas(row: np.ndarray, spans, min_text: float = 0.45) -> np.ndarray:
     """One line row (x0, y0, x1, y1, score, block, angle, kind) -> its pieces left to right as rows of the same form:
     stretches of text (kind 0 for the first piece, 3 after it) and formulas (5 / 4).  A stretch of text shorter than
-    ``min_text`` line heights is a sliver between a formula and the line's end, not text."""
+    ``min_text`` line heights is a sliver between a formula and the line's end, not text.  The last row (kind 6) is the
+    whole line once more: read as plain text, it is what the line falls back to when a formula in it is read with
+    little confidence."""
     cx, cy = 0.5 * (row[0] + row[2]), 0.5 * (row[1] + row[3])
     w, h = row[2] - row[0], row[3] - row[1]
     c, sn = np.cos(row[6]), np.sin(row[6])
@@ -273,7 +281,9 @@ def split_line_at_formulas(row: np.ndarray, spans, min_text: float = 0.45) -> np
         cur = a1
     if 0.5 * w - cur >= min_text * h:
         parts.append((cur, 0.5 * w, False, row[4]))
-    out = np.zeros((len(parts), row.shape[0]), np.float32)
+    out = np.zeros((len(parts) + 1, row.shape[0]), np.float32)
+    out[-1] = row
+    out[-1, 7] = KIND_LINE_ALT
     for k, (u, v, is_math, sc) in enumerate(parts):
         m, half = 0.5 * (u + v), 0.5 * (v - u)
         px, py = cx + m * c, cy + m * sn
@@ -563,7 +573,7 @@ class OcrEngine:
                 q = q[np.minimum(q[:, 2] - q[:, 0], q[:, 3] - q[:, 1]) >= cfg.formula_min_side_px][: cfg.max_formulas_per_page]
                 if q.shape[0] and cfg.inline_formulas:
                     # formulas inside a text line are set aside here and cut out of their line after the layout analysis
-                    _, in_line = assign_inline_formulas(r, q)
+                    _, in_line = assign_inline_formulas(r, q)         # (whatever their score: they are no display formulas)
                     inline_q = q[in_line]
                     q = q[~in_line]
                 if q.shape[0]:
@@ -639,7 +649,8 @@ class OcrEngine:
             fo = np.concatenate([fg[order[pos] - n], pos[:, None].astype(np.float32)], 1) if pos.size else np.zeros((0, 5), np.float32)
             if inline_q is not None and inline_q.shape[0]:
                 # (the pieces of a line become one line again in ``_finish``: figure positions stay as they are)
-                spans, _ = assign_inline_formulas(np.where(lines[:, 7:8] == KIND_TEXT, lines, np.nan), inline_q)
+                spans, _ = assign_inline_formulas(np.where(lines[:, 7:8] == KIND_TEXT, lines, np.nan), inline_q,
+                                                  cfg.inline_min_score)
                 if spans and self.on_gpu and pi < len(db.srcs):
                     spans = self._refine_spans(db.srcs[pi], lines, spans)
                 if spans:
@@ -1023,6 +1034,18 @@ class OcrEngine:
             cur = None                  # the line whose pieces (text, formula, text, ...) are being put together
             for k in range(b4.shape[0]):
                 gi = pos + k
+                if knd[k] == KIND_LINE_ALT:
+                    # the whole line read as text: taken when a formula cut out of it was read with little confidence
+                    # (what the detector took for a formula was text), or when nothing else of the line was kept
+                    if ok[gi] and (cur is None or cur.formula_confidence < self.cfg.inline_min_conf):
+                        alt = TextLine(tuple(float(v) for v in b4[k, :4]), texts[gi], float(confs[gi]), int(blk[k]),
+                                       float(b4[k, 4]), "text")
+                        if cur is None:
+                            r.lines.append(alt)
+                        else:
+                            r.lines[-1] = alt
+                    cur = None
+                    continue
                 if knd[k] == KIND_FORMULA:
                     cur = None
                     r.lines.append(TextLine(tuple(float(v) for v in b4[k, :4]), texts[gi], float(confs[gi]), int(blk[k]),
@@ -1041,9 +1064,13 @@ class OcrEngine:
                     cur.box = (min(cur.box[0], float(bb[0])), min(cur.box[1], float(bb[1])),
                                max(cur.box[2], float(bb[2])), max(cur.box[3], float(bb[3])))
                     cur.confidence = min(cur.confidence, float(confs[gi]))
+                    if math:
+                        cur.formula_confidence = min(cur.formula_confidence, float(confs[gi]))
                     continue
                 cur = TextLine(tuple(float(v) for v in b4[k, :4]), piece, float(confs[gi]), int(blk[k]),
                                float(b4[k, 4]), "cell" if knd[k] == KIND_CELL else "text")
+                if math:
+                    cur.formula_confidence = float(confs[gi])
                 r.lines.append(cur)
             for k in range(fg.shape[0]):
                 crop = rb.fig_crops.get((pi, k))

@@ -335,6 +335,13 @@ def test_formulas_inside_lines_are_cut_out_and_put_back_in_place():
             assert abs(l.box[0] - tb[0]) < 12 and abs(l.box[2] - tb[2]) < 12
         else:
             assert l.text == "T"
+    # formulas read with little confidence: their lines fall back to the whole line read as text
+    eng.cfg.inline_min_conf = 2.0
+    res = eng.process_pages([E.PageImage(torch.from_numpy(pg.copy()), "f", 0)])[0]
+    text_lines = [l for l in res.lines if l.kind == "text"]
+    assert len(text_lines) == len(tr.texts) and all(l.text == "T" for l in text_lines)
+    for li in tr.line_parts:
+        assert abs(text_lines[li].box[0] - tr.boxes[li][0]) < 12 and abs(text_lines[li].box[2] - tr.boxes[li][2]) < 12
 
 
 def test_inline_assignment_and_split_follow_a_skewed_line():
@@ -348,13 +355,15 @@ def test_inline_assignment_and_split_follow_a_skewed_line():
     spans, taken = E.assign_inline_formulas(line, q)
     assert taken.tolist() == [True, False] and abs(spans[0][0][0] - 520) < 1 and abs(spans[0][0][1] - 680) < 1
     parts = E.split_line_at_formulas(line[0], spans[0])
-    assert parts[:, 7].tolist() == [E.KIND_TEXT, E.KIND_MATH_CONT, E.KIND_TEXT_CONT]
+    assert parts[:, 7].tolist() == [E.KIND_TEXT, E.KIND_MATH_CONT, E.KIND_TEXT_CONT, E.KIND_LINE_ALT]
+    assert np.array_equal(parts[-1, :7], line[0, :7])                      # the whole line once more, as the fallback
+    parts = parts[:-1]
     mid = 0.5 * (parts[1, :2] + parts[1, 2:4])
     assert np.allclose(mid, [1000 + a * np.cos(th), 530 + a * np.sin(th)], atol=0.5)
     assert np.allclose(parts[:, 3] - parts[:, 1], 60) and abs((parts[:, 2] - parts[:, 0]).sum() - 1800) < 1e-3
     # a line that begins with the formula; a sliver of text at the end is dropped
     parts = E.split_line_at_formulas(line[0], [(-900.0, -700.0, 0.7), (700.0, 885.0, 0.6)])
-    assert parts[:, 7].tolist() == [E.KIND_MATH_HEAD, E.KIND_TEXT_CONT, E.KIND_MATH_CONT]
+    assert parts[:, 7].tolist() == [E.KIND_MATH_HEAD, E.KIND_TEXT_CONT, E.KIND_MATH_CONT, E.KIND_LINE_ALT]
 
 
 def test_widest_gap_picks_the_word_space_not_a_letter_gap():
