@@ -82,7 +82,12 @@ class DBNet(nn.Module):
         return self.forward_all(x)[0]
 
     def forward_all(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        """-> (text probability [B,H,W], block logits [B,2,H/4,W/4]: channel 0 figure, channel 1 display formula)."""
+        """-> (text probability [B,H,W], block logits [B,2,H/4,W/4]: channel 0 figure, channel 1 formula)."""
+        h = self.forward_features(x)
+        return self.head3(self.head2(h))[:, 0], self.fig_head(h)[:, :2]
+
+    def forward_features(self, x: torch.Tensor) -> torch.Tensor:
+        """-> the quarter-scale feature map [B,q,H/4,W/4] both heads read."""
         y = self.stem3(self.stem2(self.stem1(x)))
         feats = []
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
@@ -99,8 +104,7 @@ class DBNet(nn.Module):
         p3 = F.interpolate(self.p3(o3), scale_factor=2, mode="nearest")
         p2 = self.p2(o2)
         fuse = torch.cat([p5, p4, p3, p2], dim=1)
-        h = self.head1(fuse)
-        return self.head3(self.head2(h))[:, 0], self.fig_head(h)[:, :2]
+        return self.head1(fuse)
 
     # ------------------------------------------------------------------ inference path (NHWC bf16)
     @torch.no_grad()

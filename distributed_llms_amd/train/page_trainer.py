@@ -512,6 +512,9 @@ def main(argv=None) -> int:
     ap.add_argument("--table-share", type=float, default=0.0, help="share of the pages that carry a (ruled or unruled) table")
     ap.add_argument("--inline-share", type=float, default=0.0,
                     help="share of the layout pages whose paragraphs carry formulas inside the lines")
+    ap.add_argument("--head-only", action="store_true",
+                    help="train nothing but the detector's block head (figure / formula channels) on frozen features: the text "
+                         "map, the figure features and the recogniser stay exactly as they are")
     ap.add_argument("--rec-only", action="store_true", help="leave the detector as it is: recogniser steps only")
     ap.add_argument("--lines", type=int, default=64, help="line crops per recogniser step")
     ap.add_argument("--history", default="", help="free text recorded in train_meta.json")
@@ -551,7 +554,10 @@ def main(argv=None) -> int:
     det.train()
     rec.train()
     rec.own_conv_train = device.type == "cuda" and not args.library_convs
-    dopt, ropt = _Opt(det, args.det_lr), _Opt(rec, args.rec_lr)
+    if args.head_only:
+        det.eval()                   # batch-norm statistics stay as shipped
+        rec.eval()
+    dopt, ropt = _Opt(det.fig_head if args.head_only else det, args.det_lr), _Opt(rec, args.rec_lr)
     it = start
     prod = PageProducer(device, threads=args.threads, script_share=args.script_share, table_share=args.table_share,
                         inline_share=args.inline_share)
@@ -570,6 +576,22 @@ def main(argv=None) -> int:
             pages = [prod.get() for _ in range(3)]
             # ---- detector step
             ld = lf = 0.0
+            if args.head_only:
+                x, _, ftgt = det_batch(pages, device, per_page=4)
+                dopt.zero()
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                    with torch.no_grad():
+                        feat = det.forward_features(x)
+                    flogit = det.fig_head(feat)[:, :2]
+                lf = fig_loss(flogit, ftgt)
+                lf.backward()
+                dopt.step(it, args.steps)
+                it += 1
+                if it % 25 == 0:
+                    rec_ = {"step": it, "fig_loss": round(float(lf), 4), "elapsed_s": round(time.perf_counter() - t0, 1)}
+                    log.append(rec_)
+                    print(json.dumps(rec_), flush=True)
+                continue
             if not args.rec_only:
                 x, tgt, ftgt = det_batch(pages, device)
                 dopt.zero()
