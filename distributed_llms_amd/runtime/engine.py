@@ -165,7 +165,10 @@ class EngineConfig:
     detect_formulas: bool = True      # second channel of the block head -> formula boxes -> formula recogniser
     inline_formulas: bool = True      # formula boxes inside a text line: the line is read in pieces, ``... $x_{i}$ ...``
     inline_min_score: float = 0.5     # mean probability of the formula map over the box, below which it cuts nothing
-    inline_min_conf: float = 0.0      # mean token probability of a formula in a line, below which the line is read whole
+    inline_min_conf: float = 0.9      # mean token probability of a formula in a line, below which the line is read whole
+    # "x = 3", "(a)", "12" are read as well by the text recogniser, and the formula map fires on such tokens of ordinary
+    # prose: a formula inside a line counts when its LaTeX has a command, a subscript or a superscript
+    inline_needs_markup: bool = True
     # a display formula is 60-100 page pixels tall = 6-10 pixels of the 1/4-scale block map: smaller size floor
     frm_db: dbpost.DBPostConfig = field(default_factory=lambda: dbpost.DBPostConfig(
         bin_thresh=0.5, box_thresh=0.5, unclip_ratio=0.0, min_size=1, max_components=1024, max_boxes=64, max_angle_deg=0.0))
@@ -670,13 +673,15 @@ class OcrEngine:
             cx, cy = 0.5 * (lines[k, 0] + lines[k, 2]), 0.5 * (lines[k, 1] + lines[k, 3])
             w, h = lines[k, 2] - lines[k, 0], lines[k, 3] - lines[k, 1]
             c, sn = float(np.cos(lines[k, 6])), float(np.sin(lines[k, 6]))
-            reach = int(min(L // 2 - 1, max(8.0, 0.55 * h)))
+            # the thresholded map is wider than the formula rather than narrower: look further inwards than outwards
+            r_out, r_in = int(min(L // 3, max(6.0, 0.35 * h))), int(min(2 * L // 3 - 1, max(10.0, 0.9 * h)))
             for j, (a0, a1, _) in enumerate(sp):
                 for end, a in ((0, a0), (1, a1)):
                     if abs(abs(a) - 0.5 * w) < 2.0:          # the formula ends where the line ends
                         continue
                     bx, by = int(round(cx + a * c)), int(round(cy + a * sn))
-                    x0, x1 = max(0, bx - reach), min(W, bx + reach + 1)
+                    lo, hi = (r_out, r_in) if end == 0 else (r_in, r_out)
+                    x0, x1 = max(0, bx - lo), min(W, bx + hi + 1)
                     y0, y1 = max(0, int(by - 0.28 * h)), min(H, int(by + 0.28 * h) + 1)
                     if x1 - x0 < 8 or y1 - y0 < 2:
                         continue
@@ -1057,6 +1062,8 @@ class OcrEngine:
                         cur = None
                     continue
                 piece = ("$" + texts[gi].strip() + "$" if texts[gi].strip() else "") if math else texts[gi]
+                if math and self.cfg.inline_needs_markup and not any(c in texts[gi] for c in "\\_^"):
+                    confs[gi] = 0.0
                 if knd[k] in (KIND_TEXT_CONT, KIND_MATH_CONT) and cur is not None:
                     if piece:
                         cur.text = (cur.text + " " + piece).strip()

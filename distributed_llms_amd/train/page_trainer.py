@@ -198,6 +198,12 @@ def det_targets(truth: synth.PageTruth, hw: Tuple[int, int], scale: float, Hd: i
         hq = q[:, 3] - q[:, 1]
         q[:, 1] += 0.15 * hq
         q[:, 3] -= 0.15 * hq
+        # the polygon fill marks every map pixel the outline touches: half a map pixel off each end keeps the marked
+        # pixels to those whose centre lies in the formula (the ends matter here: they are where the line is cut)
+        half = 2.0 / scale
+        wide = (q[:, 2] - q[:, 0]) > 4 * half
+        q[wide, 0] += half
+        q[wide, 2] -= half
         frm = np.concatenate([frm.reshape(-1, 4), q], 0)
     for k, bx in enumerate((truth.figures, frm)):
         if bx.shape[0]:

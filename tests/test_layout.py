@@ -319,17 +319,22 @@ def test_formulas_inside_lines_are_cut_out_and_put_back_in_place():
     frm = TrOCR(TrOCRConfig(image_size=192, enc_dim=64, enc_layers=1, enc_heads=1, enc_mlp=128, dec_dim=64, dec_layers=1,
                             dec_heads=1, dec_ffn=128, vocab=272, max_len=24))
     eng = E.OcrEngine("cpu", _PaintedDetector(tr, pg.shape), CRNN(hidden=64, widths=(16, 32, 32, 32, 64, 64)),
-                      E.EngineConfig(det_limit_side=1344, max_batch_pages=1, formula_max_tokens=12, formula_min_side_px=4),
+                      E.EngineConfig(det_limit_side=1344, max_batch_pages=1, formula_max_tokens=12, formula_min_side_px=4,
+                                     inline_min_conf=1e-9),
                       formula_rec=frm)
     eng._strings = lambda ids, lens: ["T"] * ids.shape[0]
     frm.tokens_to_text = lambda toks, *a: ["M"] * len(toks)
+    # "formulas" without a command, subscript or superscript are what the text recogniser reads as well: whole lines
+    res = eng.process_pages([E.PageImage(torch.from_numpy(pg.copy()), "f", 0)])[0]
+    assert all(l.text == "T" for l in res.lines if l.kind == "text")
+    frm.tokens_to_text = lambda toks, *a: ["\\M"] * len(toks)
     res = eng.process_pages([E.PageImage(torch.from_numpy(pg.copy()), "f", 0)])[0]
     text_lines = [l for l in res.lines if l.kind == "text"]
     assert len(text_lines) == len(tr.texts)
     assert sum(l.kind == "equation" for l in res.lines) == tr.formulas.shape[0]
     for li, (l, t) in enumerate(zip(text_lines, tr.texts)):
         if li in tr.line_parts:
-            want = " ".join("T" if k == "t" else "$M$" for k, *_ in tr.line_parts[li])
+            want = " ".join("T" if k == "t" else "$\\M$" for k, *_ in tr.line_parts[li])
             assert l.text == want, (li, l.text, want, t)
             tb = tr.boxes[li]
             assert abs(l.box[0] - tb[0]) < 12 and abs(l.box[2] - tb[2]) < 12
