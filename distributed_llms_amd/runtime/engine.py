@@ -169,6 +169,7 @@ class EngineConfig:
     # "x = 3", "(a)", "12" are read as well by the text recogniser, and the formula map fires on such tokens of ordinary
     # prose: a formula inside a line counts when its LaTeX has a command, a subscript or a superscript
     inline_needs_markup: bool = True
+    inline_inset: float = 0.5         # line heights the formula map overshoots a formula's ends by (see ``_refine_spans``)
     # a display formula is 60-100 page pixels tall = 6-10 pixels of the 1/4-scale block map: smaller size floor
     frm_db: dbpost.DBPostConfig = field(default_factory=lambda: dbpost.DBPostConfig(
         bin_thresh=0.5, box_thresh=0.5, unclip_ratio=0.0, min_size=1, max_components=1024, max_boxes=64, max_angle_deg=0.0))
@@ -319,7 +320,7 @@ def widest_gap(profile: np.ndarray, centre: int, min_run: int = 3) -> Optional[i
             e += 1
         if e - k >= min_run:
             mid = (k + e - 1) // 2
-            key = (e - k) - 0.35 * abs(mid - centre)
+            key = (e - k) - 0.15 * abs(mid - centre)
             if best is None or key > best_key:
                 best, best_key = mid, key
         k = e
@@ -574,10 +575,11 @@ class OcrEngine:
             if frms is not None and frms[pi].shape[0]:
                 q = frms[pi]
                 q = q[np.minimum(q[:, 2] - q[:, 0], q[:, 3] - q[:, 1]) >= cfg.formula_min_side_px][: cfg.max_formulas_per_page]
-                if q.shape[0] and cfg.inline_formulas:
-                    # formulas inside a text line are set aside here and cut out of their line after the layout analysis
-                    _, in_line = assign_inline_formulas(r, q)         # (whatever their score: they are no display formulas)
-                    inline_q = q[in_line]
+                if q.shape[0]:
+                    # formulas inside a text line are set aside here (whatever their score: they are no display formulas)
+                    # and, with ``inline_formulas``, cut out of their line after the layout analysis
+                    _, in_line = assign_inline_formulas(r, q)
+                    inline_q = q[in_line] if cfg.inline_formulas else None
                     q = q[~in_line]
                 if q.shape[0]:
                     # the text detector also fires on the pieces of a formula: what lies inside a formula box is dropped
@@ -663,25 +665,28 @@ class OcrEngine:
         return out
 
     def _refine_spans(self, src: torch.Tensor, lines: np.ndarray, spans: dict) -> dict:
-        """The formula map has a quarter of the detector's resolution: +-10 page pixels at the ends of a formula, a third
-        of a letter.  Move every end to the middle of the widest gap between glyphs near it (the word space), read from
-        the page pixels: the darkest sample of each pixel column over the middle of the line."""
+        """The formula map has a quarter of the detector's resolution and its thresholded regions overshoot a formula's
+        ends by about half a line height: cutting there would clip the neighbouring words.  Move every end to the
+        middle of the widest gap between glyphs near it (the word space), read from the page pixels: the darkest sample
+        of each pixel column over the middle of the line, searched around a point ``inline_inset`` line heights in."""
+        cfg = self.cfg
         H, W = int(src.shape[0]), int(src.shape[1])
-        L = 96
+        L = 128
         jobs, profs = [], []
         for k, sp in spans.items():
             cx, cy = 0.5 * (lines[k, 0] + lines[k, 2]), 0.5 * (lines[k, 1] + lines[k, 3])
             w, h = lines[k, 2] - lines[k, 0], lines[k, 3] - lines[k, 1]
             c, sn = float(np.cos(lines[k, 6])), float(np.sin(lines[k, 6]))
-            # the thresholded map is wider than the formula rather than narrower: look further inwards than outwards
-            r_out, r_in = int(min(L // 3, max(6.0, 0.35 * h))), int(min(2 * L // 3 - 1, max(10.0, 0.9 * h)))
+            # the thresholded map reaches about half a line height beyond the formula at either end (measured on the
+            # trained detector: 25 - 35 page pixels): start the search that much further in
+            reach = int(min(L // 2 - 1, max(10.0, 0.8 * h)))
             for j, (a0, a1, _) in enumerate(sp):
-                for end, a in ((0, a0), (1, a1)):
-                    if abs(abs(a) - 0.5 * w) < 2.0:          # the formula ends where the line ends
+                ins = min(cfg.inline_inset * h, 0.3 * (a1 - a0))
+                for end, a in ((0, a0 + ins), (1, a1 - ins)):
+                    if abs(abs(a0 if end == 0 else a1) - 0.5 * w) < 2.0:      # the formula ends where the line ends
                         continue
                     bx, by = int(round(cx + a * c)), int(round(cy + a * sn))
-                    lo, hi = (r_out, r_in) if end == 0 else (r_in, r_out)
-                    x0, x1 = max(0, bx - lo), min(W, bx + hi + 1)
+                    x0, x1 = max(0, bx - reach), min(W, bx + reach + 1)
                     y0, y1 = max(0, int(by - 0.28 * h)), min(H, int(by + 0.28 * h) + 1)
                     if x1 - x0 < 8 or y1 - y0 < 2:
                         continue
@@ -690,15 +695,15 @@ class OcrEngine:
                         strip = strip[..., 0]
                     pr = strip.amin(0)
                     profs.append(torch.nn.functional.pad(pr, (0, L - pr.shape[0])))
-                    jobs.append((k, j, end, x0 - bx, int(pr.shape[0])))
+                    jobs.append((k, j, end, x0 - bx, int(pr.shape[0]), ins))
         if not jobs:
             return spans
         host = torch.stack(profs).cpu().numpy()
         out = {k: [list(t) for t in sp] for k, sp in spans.items()}
-        for row, (k, j, end, off, n) in zip(host, jobs):
+        for row, (k, j, end, off, n, ins) in zip(host, jobs):
             g = widest_gap(row[:n], -off)
-            if g is not None:
-                out[k][j][end] += float(g + off)              # along the (nearly level) line: one column = one pixel
+            if g is not None:                                 # along the (nearly level) line: one column = one pixel
+                out[k][j][end] += float(g + off) + (ins if end == 0 else -ins)
         return {k: [tuple(t) for t in sp if t[1] - t[0] >= 4.0] for k, sp in out.items()}
 
     # ------------------------------------------------------------------ recognition stage
