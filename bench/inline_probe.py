@@ -19,7 +19,7 @@ from distributed_llms_amd.train.trainer import _edit_distance
 wd = sys.argv[1] if len(sys.argv) > 1 else "weights"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 fonts = synth.HELD_OUT_FONTS if len(sys.argv) > 3 and sys.argv[3] == "held_out" else synth.TRAIN_FONTS
-ecfg = dict(max_batch_pages=4)
+ecfg = dict(max_batch_pages=4, inline_formulas=True)
 if len(sys.argv) > 4:
     ecfg["inline_min_conf"] = float(sys.argv[4])
 if len(sys.argv) > 5:

@@ -165,7 +165,7 @@ class Supervisor:
 
         st = Settings.from_env(dotenv=os.environ.get("OCR_DOTENV", ".env"))
         cfg = dict(det_limit_side=st.det_limit_side, rec_height=st.rec_height, max_batch_pages=st.max_batch_pages,
-                   use_hip_graphs=st.use_hip_graphs)
+                   use_hip_graphs=st.use_hip_graphs, inline_formulas=st.inline_formulas)
         if self.stub:
             return {"model": "stub", "pages_per_s": self.stub_pages_per_s, "cfg": dict(max_batch_pages=st.max_batch_pages)}
         return {"model": "full", "cfg": cfg, "weights_dir": st.weights_dir, "recognizer": st.recognizer}

@@ -142,6 +142,7 @@ class Settings:
     doc_deadline_s: float = 600.0
     hbm_budget_gb: float = 200.0
     use_hip_graphs: bool = True
+    inline_formulas: bool = False    # formulas inside text lines are cut out and read as LaTeX ($...$ in the line's text)
     node_id: str = field(default_factory=lambda: os.uname().nodename)
     fault_inject: str = ""
     force_pool: bool = False         # use the worker-process pool even with a single GPU
@@ -181,6 +182,7 @@ class Settings:
             doc_deadline_s=_get_float(e, "OCR_DOC_DEADLINE_S", 600.0),
             hbm_budget_gb=_get_float(e, "OCR_HBM_BUDGET_GB", 200.0),
             use_hip_graphs=_get_bool(e, "OCR_USE_HIP_GRAPHS", True),
+            inline_formulas=_get_bool(e, "OCR_INLINE_FORMULAS", False),
             fault_inject=e.get("FAULT_INJECT", ""),
             force_pool=_get_bool(e, "OCR_FORCE_POOL", False),
             worker_sockets=e.get("OCR_WORKER_SOCKETS") or None,

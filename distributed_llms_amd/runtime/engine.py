@@ -163,7 +163,10 @@ class EngineConfig:
     fig_max_page_share: float = 0.4   # a "figure" that covers more of the page than this is a tinted page, not a figure
     fig_max_lines: int = 8            # ... and one that holds this many text lines is a text region
     detect_formulas: bool = True      # second channel of the block head -> formula boxes -> formula recogniser
-    inline_formulas: bool = True      # formula boxes inside a text line: the line is read in pieces, ``... $x_{i}$ ...``
+    # formula boxes inside a text line: the line is read in pieces, ``... $x_{i}$ ...``.  Off by default: it needs the
+    # detector trained for it (``dbnet_inline.safetensors``, chosen by ``runtime.workers.build_engine`` when this is set),
+    # which finds three formulas in four and takes one ordinary line in 200 for one (bench/inline_probe.py)
+    inline_formulas: bool = False
     inline_min_score: float = 0.5     # mean probability of the formula map over the box, below which it cuts nothing
     inline_min_conf: float = 0.9      # mean token probability of a formula in a line, below which the line is read whole
     # "x = 3", "(a)", "12" are read as well by the text recogniser, and the formula map fires on such tokens of ordinary
@@ -575,11 +578,11 @@ class OcrEngine:
             if frms is not None and frms[pi].shape[0]:
                 q = frms[pi]
                 q = q[np.minimum(q[:, 2] - q[:, 0], q[:, 3] - q[:, 1]) >= cfg.formula_min_side_px][: cfg.max_formulas_per_page]
-                if q.shape[0]:
+                if q.shape[0] and cfg.inline_formulas:
                     # formulas inside a text line are set aside here (whatever their score: they are no display formulas)
-                    # and, with ``inline_formulas``, cut out of their line after the layout analysis
+                    # and cut out of their line after the layout analysis
                     _, in_line = assign_inline_formulas(r, q)
-                    inline_q = q[in_line] if cfg.inline_formulas else None
+                    inline_q = q[in_line]
                     q = q[~in_line]
                 if q.shape[0]:
                     # the text detector also fires on the pieces of a formula: what lies inside a formula box is dropped

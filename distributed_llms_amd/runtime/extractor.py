@@ -198,7 +198,8 @@ def make_extractor(settings, image_writer: Optional[LocalFileWriter] = None) -> 
         if settings.num_gpus != 0:
             want = min(want, len(ids)) if settings.num_gpus > 0 else len(ids)
     cfg = dict(det_limit_side=settings.det_limit_side, rec_height=settings.rec_height,
-               max_batch_pages=settings.max_batch_pages, use_hip_graphs=settings.use_hip_graphs)
+               max_batch_pages=settings.max_batch_pages, use_hip_graphs=settings.use_hip_graphs,
+               inline_formulas=getattr(settings, "inline_formulas", False))
     if want <= 0 or ngpu_visible == 0:
         logger.warning("no GPU requested/visible: OCR runs on the CPU oracle path (slow; text PDFs are unaffected)")
         spec_model = getattr(settings, "cpu_model", "full")

@@ -86,7 +86,12 @@ def build_engine(device: str, engine_spec: Dict) -> "object":
     if wd and str(wd).lower() != "none" and engine_spec.get("model", "full") == "full":
         from ..utils.weights import load_model_weights
 
-        load_model_weights(det, os.path.join(wd, "dbnet.safetensors"), strict=False)
+        det_file = "dbnet.safetensors"
+        if cfg.inline_formulas and os.path.exists(os.path.join(wd, "dbnet_inline.safetensors")):
+            # the detector whose formula channel also marks formulas inside text lines (train/page_trainer.py
+            # --inline-share); the default one marks display formulas only
+            det_file = "dbnet_inline.safetensors"
+        load_model_weights(det, os.path.join(wd, det_file), strict=False)
         rec_file = os.path.join(wd, "trocr.safetensors" if kind == "trocr" else "crnn.safetensors")
         if kind != "trocr" or os.path.exists(rec_file):
             load_model_weights(rec, rec_file, strict=False)

@@ -445,7 +445,7 @@ def held_out_pages(seeds, skew=3.0, fonts=None):
     return out
 
 
-def evaluate(det, rec, device, seeds, verbose=False, formula_weights=None):
+def evaluate(det, rec, device, seeds, verbose=False, formula_weights=None, inline=False):
     """Three held-out sets: the benchmark's page family (unseen seeds), layout pages in the training fonts, layout
     pages in held-out fonts at +-3 degrees of skew."""
     from ..runtime.engine import EngineConfig, OcrEngine
@@ -457,7 +457,7 @@ def evaluate(det, rec, device, seeds, verbose=False, formula_weights=None):
 
         formula = TrOCR(formula_config())
         load_model_weights(formula, formula_weights)
-    eng = OcrEngine(device, det, rec, EngineConfig(max_batch_pages=4), formula_rec=formula)
+    eng = OcrEngine(device, det, rec, EngineConfig(max_batch_pages=4, inline_formulas=inline), formula_rec=formula)
     out = {}
     out["plain"] = evaluate_pages(eng, [synth.render_page(sd) for sd in seeds[:4]], verbose)
     out["layout_train_fonts"] = evaluate_pages(eng, [render_training_page(sd, plain_share=0.0) for sd in seeds], verbose)
@@ -476,10 +476,11 @@ def evaluate(det, rec, device, seeds, verbose=False, formula_weights=None):
     out["formula_pages"] = evaluate_pages(eng, [synth.render_layout_page(sd, fonts=synth.TRAIN_FONTS, formulas=0.8,
                                                                          layout=synth.LAYOUTS[k % 3])
                                                 for k, sd in enumerate(seeds[:4])], verbose)
-    out["inline_formula_pages"] = evaluate_pages(eng, [synth.render_layout_page(sd, fonts=synth.TRAIN_FONTS, inline=0.35,
-                                                                                layout=synth.LAYOUTS[k % 3],
-                                                                                skew=1.5 * (k % 3 - 1))
-                                                       for k, sd in enumerate(seeds[:6])], verbose)
+    if inline:
+        out["inline_formula_pages"] = evaluate_pages(eng, [synth.render_layout_page(sd, fonts=synth.TRAIN_FONTS, inline=0.35,
+                                                                                    layout=synth.LAYOUTS[k % 3],
+                                                                                    skew=1.5 * (k % 3 - 1))
+                                                           for k, sd in enumerate(seeds[:6])], verbose)
     det.train()
     rec.train()
     return out
@@ -624,7 +625,8 @@ def main(argv=None) -> int:
                 log.append(rec_)
                 print(json.dumps(rec_), flush=True)
             if it % args.eval_every == 0 or it == args.steps:
-                ev = evaluate(det, rec, device, seeds=[900_001, 900_002, 900_003, 900_004], verbose=True, formula_weights=fw)
+                ev = evaluate(det, rec, device, seeds=[900_001, 900_002, 900_003, 900_004], verbose=True, formula_weights=fw,
+                              inline=args.inline_share > 0)
                 print(json.dumps({"step": it, "eval": ev}), flush=True)
                 save_bf16(det, dp)
                 save_bf16(rec, rp)
@@ -633,7 +635,7 @@ def main(argv=None) -> int:
         prod.stop()
         alive.set()
     ev = evaluate(det, rec, device, seeds=[900_001, 900_002, 900_003, 900_004, 900_005, 900_006, 900_007, 900_008], verbose=True,
-                  formula_weights=fw)
+                  formula_weights=fw, inline=args.inline_share > 0)
     save_bf16(det, dp)
     save_bf16(rec, rp)
     write_meta(args.out, it, ev, log, rec.charset, args.history)

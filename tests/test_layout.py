@@ -320,7 +320,7 @@ def test_formulas_inside_lines_are_cut_out_and_put_back_in_place():
                             dec_heads=1, dec_ffn=128, vocab=272, max_len=24))
     eng = E.OcrEngine("cpu", _PaintedDetector(tr, pg.shape), CRNN(hidden=64, widths=(16, 32, 32, 32, 64, 64)),
                       E.EngineConfig(det_limit_side=1344, max_batch_pages=1, formula_max_tokens=12, formula_min_side_px=4,
-                                     inline_min_conf=1e-9),
+                                     inline_formulas=True, inline_min_conf=1e-9),
                       formula_rec=frm)
     eng._strings = lambda ids, lens: ["T"] * ids.shape[0]
     frm.tokens_to_text = lambda toks, *a: ["M"] * len(toks)
