@@ -1,5 +1,5 @@
 """Formulas inside text lines, through the engine: how many are found, how well they and the text around them are read
-(``python bench/inline_probe.py [WEIGHTS_DIR] [N_PAGES] [train|held_out] [INLINE_MIN_CONF] [INLINE_MIN_SCORE]``).  First line the summary, then one line per
+(``python bench/inline_probe.py [WEIGHTS_DIR] [N_PAGES] [train|held_out] [INLINE_MIN_CONF] [INLINE_MIN_SCORE] [INLINE_INSET]``).  First line the summary, then one line per
 text line that was not read exactly."""
 import json
 import os
@@ -24,6 +24,8 @@ if len(sys.argv) > 4:
     ecfg["inline_min_conf"] = float(sys.argv[4])
 if len(sys.argv) > 5:
     ecfg["inline_min_score"] = float(sys.argv[5])
+if len(sys.argv) > 6:
+    ecfg["inline_inset"] = float(sys.argv[6])
 eng = build_engine("cuda:0", {"model": "full", "weights_dir": wd, "cfg": ecfg})
 pages = []
 for k in range(n):

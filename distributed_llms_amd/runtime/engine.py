@@ -252,10 +252,18 @@ def assign_inline_formulas(lines: np.ndarray, q: np.ndarray, min_score: float = 
             along, across = dx * c + dy * sn, -dx * sn + dy * c
             ok = ((np.abs(along) <= 0.5 * w) & (np.abs(across) <= 0.5 * h) & (w >= qw + 1.0 * h) & (qh <= 1.3 * h) &
                   (w >= 2.0 * h))
-            if not ok.any():
-                continue
-            i = int(np.argmin(np.where(ok, np.abs(across), np.inf)))
-            a0, a1 = max(-0.5 * w[i], along[i] - 0.5 * qw), min(0.5 * w[i], along[i] + 0.5 * qw)
+            if ok.any():
+                i = int(np.argmin(np.where(ok, np.abs(across), np.inf)))
+                a0, a1 = max(-0.5 * w[i], along[i] - 0.5 * qw), min(0.5 * w[i], along[i] + 0.5 * qw)
+            else:
+                # a line that begins or ends with a formula: the text detector tends to stop where the words stop, and
+                # the formula lies just beyond the line's end, on its baseline
+                gap = np.abs(along) - 0.5 * w - 0.5 * qw
+                near = (gap <= 1.2 * h) & (np.abs(across) <= 0.35 * h) & (qh <= 1.5 * h) & (w >= 1.5 * h) & (qw <= 12.0 * h)
+                if not near.any():
+                    continue
+                i = int(np.argmin(np.where(near, gap, np.inf)))
+                a0, a1 = along[i] - 0.5 * qw, along[i] + 0.5 * qw
             if a1 - a0 < 4.0:
                 continue
             taken[j] = True
@@ -277,7 +285,10 @@ def split_line_at_formulas(row: np.ndarray, spans, min_text: float = 0.45) -> np
     w, h = row[2] - row[0], row[3] - row[1]
     c, sn = np.cos(row[6]), np.sin(row[6])
     parts = []
-    cur = -0.5 * w
+    # (a formula beyond the line's end - the line begins or ends with it - makes the line that much longer)
+    lo = min([-0.5 * w] + [a0 for a0, _, _ in spans])
+    hi = max([0.5 * w] + [a1 for _, a1, _ in spans])
+    cur = lo
     for a0, a1, sc in spans:
         a0 = max(a0, cur)
         if a1 - a0 < 4.0:
@@ -286,10 +297,12 @@ def split_line_at_formulas(row: np.ndarray, spans, min_text: float = 0.45) -> np
             parts.append((cur, a0, False, row[4]))
         parts.append((a0, a1, True, sc))
         cur = a1
-    if 0.5 * w - cur >= min_text * h:
-        parts.append((cur, 0.5 * w, False, row[4]))
+    if hi - cur >= min_text * h:
+        parts.append((cur, hi, False, row[4]))
     out = np.zeros((len(parts) + 1, row.shape[0]), np.float32)
     out[-1] = row
+    m, half = 0.5 * (lo + hi), 0.5 * (hi - lo)
+    out[-1, :4] = (cx + m * c - half, cy + m * sn - 0.5 * h, cx + m * c + half, cy + m * sn + 0.5 * h)
     out[-1, 7] = KIND_LINE_ALT
     for k, (u, v, is_math, sc) in enumerate(parts):
         m, half = 0.5 * (u + v), 0.5 * (v - u)

@@ -371,6 +371,20 @@ def test_inline_assignment_and_split_follow_a_skewed_line():
     assert parts[:, 7].tolist() == [E.KIND_MATH_HEAD, E.KIND_TEXT_CONT, E.KIND_MATH_CONT, E.KIND_LINE_ALT]
 
 
+def test_a_formula_just_beyond_a_lines_end_joins_that_line():
+    """The text detector tends to stop where the words stop: a formula on the same baseline within a line height of the
+    line's end is the line's first / last piece, and the line (and its fallback) grows to hold it."""
+    from distributed_llms_amd.runtime import engine as E
+
+    line = np.array([[400, 500, 1900, 560, 0.9, 0, 0.0, 0]], np.float32)
+    q = np.array([[150, 510, 380, 550, 0.8], [1930, 505, 2100, 555, 0.8], [150, 700, 380, 750, 0.8]], np.float32)
+    spans, taken = E.assign_inline_formulas(line, q)
+    assert taken.tolist() == [True, True, False]                 # the third lies a line further down: a display formula
+    parts = E.split_line_at_formulas(line[0], spans[0])
+    assert parts[:, 7].tolist() == [E.KIND_MATH_HEAD, E.KIND_TEXT_CONT, E.KIND_MATH_CONT, E.KIND_LINE_ALT]
+    assert parts[:, 0].tolist() == [150, 380, 1930, 150] and parts[:, 2].tolist() == [380, 1930, 2100, 2100]
+
+
 def test_widest_gap_picks_the_word_space_not_a_letter_gap():
     from distributed_llms_amd.runtime.engine import widest_gap
 
