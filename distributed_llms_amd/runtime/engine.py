@@ -165,14 +165,16 @@ class EngineConfig:
     detect_formulas: bool = True      # second channel of the block head -> formula boxes -> formula recogniser
     # formula boxes inside a text line: the line is read in pieces, ``... $x_{i}$ ...``.  Off by default: it needs the
     # detector trained for it (``dbnet_inline.safetensors``, chosen by ``runtime.workers.build_engine`` when this is set),
-    # which finds three formulas in four and takes one ordinary line in 200 for one (bench/inline_probe.py)
+    # which finds four formulas in five and takes one ordinary line in 170 for one (bench/inline_probe.py)
     inline_formulas: bool = False
     inline_min_score: float = 0.5     # mean probability of the formula map over the box, below which it cuts nothing
     inline_min_conf: float = 0.9      # mean token probability of a formula in a line, below which the line is read whole
     # "x = 3", "(a)", "12" are read as well by the text recogniser, and the formula map fires on such tokens of ordinary
     # prose: a formula inside a line counts when its LaTeX has a command, a subscript or a superscript
     inline_needs_markup: bool = True
-    inline_inset: float = 0.5         # line heights the formula map overshoots a formula's ends by (see ``_refine_spans``)
+    # line heights inside the detected end of a formula around which its true end is searched (``_refine_spans``; the
+    # map overshoots by 0.3 - 0.6: of 266 formulas 140 / 148 / 145 / 130 / 108 are read exactly at 0.15 / 0.25 / 0.35 / 0.5 / 0.65)
+    inline_inset: float = 0.25
     # a display formula is 60-100 page pixels tall = 6-10 pixels of the 1/4-scale block map: smaller size floor
     frm_db: dbpost.DBPostConfig = field(default_factory=lambda: dbpost.DBPostConfig(
         bin_thresh=0.5, box_thresh=0.5, unclip_ratio=0.0, min_size=1, max_components=1024, max_boxes=64, max_angle_deg=0.0))
@@ -693,8 +695,8 @@ class OcrEngine:
             cx, cy = 0.5 * (lines[k, 0] + lines[k, 2]), 0.5 * (lines[k, 1] + lines[k, 3])
             w, h = lines[k, 2] - lines[k, 0], lines[k, 3] - lines[k, 1]
             c, sn = float(np.cos(lines[k, 6])), float(np.sin(lines[k, 6]))
-            # the thresholded map reaches about half a line height beyond the formula at either end (measured on the
-            # trained detector: 25 - 35 page pixels): start the search that much further in
+            # the thresholded map reaches beyond the formula at either end (measured on the trained detector: 25 - 35
+            # page pixels on average, half a line height): start the search ``inline_inset`` line heights further in
             reach = int(min(L // 2 - 1, max(10.0, 0.8 * h)))
             for j, (a0, a1, _) in enumerate(sp):
                 ins = min(cfg.inline_inset * h, 0.3 * (a1 - a0))
