@@ -261,7 +261,9 @@ def assign_inline_formulas(lines: np.ndarray, q: np.ndarray, min_score: float = 
                 # a line that begins or ends with a formula: the text detector tends to stop where the words stop, and
                 # the formula lies just beyond the line's end, on its baseline
                 gap = np.abs(along) - 0.5 * w - 0.5 * qw
-                near = (gap <= 1.2 * h) & (np.abs(across) <= 0.35 * h) & (qh <= 1.5 * h) & (w >= 1.5 * h) & (qw <= 12.0 * h)
+                # (beyond it: what the text detector finds INSIDE a display formula, its pieces, has a large negative gap)
+                near = ((gap <= 1.2 * h) & (gap >= -0.5 * h) & (np.abs(across) <= 0.35 * h) & (qh <= 1.5 * h) &
+                        (w >= 1.5 * h) & (qw <= 12.0 * h))
                 if not near.any():
                     continue
                 i = int(np.argmin(np.where(near, gap, np.inf)))

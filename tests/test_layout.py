@@ -383,6 +383,10 @@ def test_a_formula_just_beyond_a_lines_end_joins_that_line():
     parts = E.split_line_at_formulas(line[0], spans[0])
     assert parts[:, 7].tolist() == [E.KIND_MATH_HEAD, E.KIND_TEXT_CONT, E.KIND_MATH_CONT, E.KIND_LINE_ALT]
     assert parts[:, 0].tolist() == [150, 380, 1930, 150] and parts[:, 2].tolist() == [380, 1930, 2100, 2100]
+    # the pieces of a display formula that the text detector reports lie inside the formula's box: they do not claim it
+    piece = np.array([[500, 1010, 700, 1060, 0.9, 0, 0.0, 0]], np.float32)
+    spans, taken = E.assign_inline_formulas(piece, np.array([[400, 1000, 900, 1070, 0.9]], np.float32))
+    assert not spans and not taken.any()
 
 
 def test_widest_gap_picks_the_word_space_not_a_letter_gap():
