@@ -122,7 +122,51 @@ __global__ __launch_bounds__(256) void db_head_fused_kernel(DbHeadArgs p) {
   }
 }
 
+// Block head tail: the [N, 8] logits of the quarter-scale block head -> probability map (bf16) and bit mask of the
+// first one or two channels (figures, formulas), each as its own dense [N] plane for the connected-component pass.
+// One 16-byte load per pixel; a wave writes 128 contiguous bytes of probabilities and 64 of mask per channel.
+struct BlockSplitArgs {
+  const bf16_t* logits;   // [N, 8]
+  bf16_t* prob[2];        // [N] each
+  uint8_t* mask[2];
+  long long n;
+  int nch;
+};
+
+__global__ __launch_bounds__(256) void block_head_split_kernel(BlockSplitArgs p) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += stride) {
+    const bf16x8 v = as_bf16x8(*(const u32x4*)(p.logits + i * 8));
+    const float l0 = (float)v[0], l1 = (float)v[1];
+    p.prob[0][i] = (bf16_t)(1.f / (1.f + __expf(-l0)));
+    p.mask[0][i] = l0 > 0.f ? 1 : 0;
+    if (p.nch > 1) {
+      p.prob[1][i] = (bf16_t)(1.f / (1.f + __expf(-l1)));
+      p.mask[1][i] = l1 > 0.f ? 1 : 0;
+    }
+  }
+}
+
 }  // namespace
+
+// Host contract: logits [N, 8] bf16 contiguous and 16-byte aligned; prob planes [N] bf16, mask planes [N] u8; the second
+// pair may be null (one channel).
+extern "C" int dlamd_block_head_split(const void* logits, void* prob0, void* mask0, void* prob1, void* mask1, long long n,
+                                      hipStream_t stream) {
+  if (!logits || !prob0 || !mask0 || n <= 0) return -1;
+  if ((prob1 == nullptr) != (mask1 == nullptr)) return -2;
+  if (((uintptr_t)logits & 15) != 0) return -3;
+  BlockSplitArgs a;
+  a.logits = (const bf16_t*)logits;
+  a.prob[0] = (bf16_t*)prob0; a.mask[0] = (uint8_t*)mask0;
+  a.prob[1] = (bf16_t*)prob1; a.mask[1] = (uint8_t*)mask1;
+  a.n = n;
+  a.nch = prob1 ? 2 : 1;
+  long long wgs = (n + 255) / 256;
+  if (wgs > 4096) wgs = 4096;
+  hipLaunchKernelGGL(block_head_split_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -9;
+}
 
 // Host contract: h [B,Hq,Wq,64] bf16 contiguous, Wq even, prob / mask [B,4Hq,4Wq] contiguous; all pointers 16-byte aligned.
 extern "C" int dlamd_db_head_fused(const void* h, const void* w2, const float* b2, const void* a2frag, const float* b3,

@@ -81,6 +81,7 @@ def _declare(l: ctypes.CDLL) -> None:
     sig("dlamd_gemm8_serves", [i] * 12)
     sig("dlamd_gemm8", [vp, vp, vp, vp, vp] + [i] * 18 + [vp])
     sig("dlamd_db_head_fused", [vp, vp, vp, vp, vp, vp, vp, i, i, i, f, vp])
+    sig("dlamd_block_head_split", [vp, vp, vp, vp, vp, ll, vp])
     sig("dlamd_resample", [vp, i, vp, i, i, f, f, f, f, f, f, vp])
     sig("dlamd_resample_stem", [vp, i, i, i, f, f, f, f, f, f, vp, vp, vp, i, i, vp])
     sig("dlamd_db_postprocess", [vp] * 10 + [i, i, i, i, i, f, f, i, f, vp, vp, vp])

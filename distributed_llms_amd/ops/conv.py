@@ -366,3 +366,24 @@ def db_head_fused(h: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, a2frag: t
                                            _loader.stream_ptr())
     _loader.check(rc, "dlamd_db_head_fused")
     return prob, mask
+
+
+def block_head_split(logits: torch.Tensor, channels: int = 2):
+    """Block-head logits [B, H, W, 8] bf16 -> per channel (figures, formulas) the probability map [B, H, W] bf16 and the bit
+    mask [B, H, W] u8 (logit > 0) the connected-component pass reads: one kernel instead of slicing, sigmoid, compare
+    and two casts per channel.  -> [(prob, mask)] * channels."""
+    assert logits.dtype == torch.bfloat16 and logits.is_contiguous() and logits.shape[-1] == 8 and channels in (1, 2)
+    shape = tuple(logits.shape[:-1])
+    if not logits.is_cuda:
+        out = []
+        for c in range(channels):
+            l = logits[..., c].float()
+            out.append((torch.sigmoid(l).to(torch.bfloat16).contiguous(), (l > 0).to(torch.uint8).contiguous()))
+        return out
+    out = [(torch.empty(shape, dtype=torch.bfloat16, device=logits.device), torch.empty(shape, dtype=torch.uint8, device=logits.device))
+           for _ in range(channels)]
+    p1, m1 = out[1] if channels == 2 else (None, None)
+    rc = _loader.lib().dlamd_block_head_split(_loader.ptr(logits), _loader.ptr(out[0][0]), _loader.ptr(out[0][1]),
+                                              _loader.ptr(p1), _loader.ptr(m1), logits.numel() // 8, _loader.stream_ptr())
+    _loader.check(rc, "dlamd_block_head_split")
+    return out

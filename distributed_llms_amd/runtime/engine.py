@@ -33,6 +33,7 @@ import torch
 
 from ..models.crnn import CRNN
 from ..models.dbnet import DBNet
+from ..ops import conv as conv_ops
 from ..ops import dbpost
 from ..ops import jpeg as jpeg_ops
 from ..ops import lstm as lstm_ops
@@ -475,11 +476,10 @@ class OcrEngine:
                 x = self._resample(regions, Hd, Wd, rs.IMAGENET_MEAN, rs.IMAGENET_STD)
             if figs:
                 prob, mask, fig = det_infer(x, with_figures=True)
-                fl = fig[..., 0].float()
-                fprob, fmask = torch.sigmoid(fl).to(torch.bfloat16).contiguous(), (fl > 0).to(torch.uint8).contiguous()
+                planes = conv_ops.block_head_split(fig.contiguous(), 2 if frm else 1)
+                fprob, fmask = planes[0]
                 if frm:
-                    ql = fig[..., 1].float()
-                    qprob, qmask = torch.sigmoid(ql).to(torch.bfloat16).contiguous(), (ql > 0).to(torch.uint8).contiguous()
+                    qprob, qmask = planes[1]
             else:
                 prob, mask = det_infer(x)
             scale = torch.tensor([[p.hw[1] / g[1], p.hw[0] / g[0]] for p, g in zip(pages, geo)],

@@ -575,3 +575,21 @@ def test_linear_train_function_matches_autograd(M, K, N):
     close(x.grad, xr.grad, "dx")
     close(w.grad, wr.grad, "dw")            # the reduction over M rows accumulates in fp32 on both sides
     close(b.grad, br.grad, "db")
+
+
+def test_block_head_split_matches_sigmoid_and_threshold():
+    """Block-head logits -> probability planes and bit masks of the figure / formula channels in one kernel, against
+    sigmoid and compare in fp32 (odd pixel count, one and two channels)."""
+    from distributed_llms_amd.ops import conv as C
+
+    torch.manual_seed(3)
+    lg = (torch.randn(3, 37, 29, 8, device="cuda") * 4).to(torch.bfloat16)
+    lg[0, 0, :8, 0] = torch.tensor([0.0, -0.0, 1e-3, -1e-3, 30.0, -30.0, 88.0, -88.0], device="cuda").to(torch.bfloat16)
+    for nch in (1, 2):
+        out = C.block_head_split(lg, nch)
+        assert len(out) == nch
+        for c, (prob, mask) in enumerate(out):
+            ref = torch.sigmoid(lg[..., c].float())
+            assert prob.dtype == torch.bfloat16 and mask.dtype == torch.uint8 and prob.shape == lg.shape[:-1]
+            assert (prob.float() - ref).abs().max().item() <= 4e-3          # bf16 rounding of a value in [0, 1]
+            assert torch.equal(mask, (lg[..., c].float() > 0).to(torch.uint8))
