@@ -1,4 +1,5 @@
 """Worker pool on CPU: page sharding over 2 worker processes, ordered gather, dead-worker recovery."""
+import os
 import time
 
 import numpy as np
@@ -160,3 +161,26 @@ def test_gpu_worker_processes_shard_a_scanned_document():
     ref = DocumentPipeline(build_engine("cuda:0", spec)).process_pdf(pdf, "ref")
     assert [len(p.lines) for p in doc.pages] == [len(p.lines) for p in ref.pages]
     assert doc.text == ref.text
+
+
+def test_inline_formula_setting_selects_the_detector_trained_for_it(tmp_path, monkeypatch):
+    """OCR_INLINE_FORMULAS reaches the engine configuration, and an engine built with it loads ``dbnet_inline.safetensors``
+    (when the weights directory has one) instead of ``dbnet.safetensors``."""
+    from distributed_llms_amd.config import Settings
+    from distributed_llms_amd.runtime import workers
+    from distributed_llms_amd.utils import weights as W
+
+    assert Settings.from_env(env={}).inline_formulas is False
+    assert Settings.from_env(env={"OCR_INLINE_FORMULAS": "true"}).inline_formulas is True
+    for name in ("dbnet.safetensors", "dbnet_inline.safetensors", "crnn.safetensors"):
+        (tmp_path / name).write_bytes(b"")
+    loaded = []
+    monkeypatch.setattr(W, "load_model_weights", lambda model, path, strict=True: loaded.append(os.path.basename(path)))
+    for flag, want in ((False, "dbnet.safetensors"), (True, "dbnet_inline.safetensors")):
+        loaded.clear()
+        eng = workers.build_engine("cpu", {"model": "full", "weights_dir": str(tmp_path), "cfg": dict(inline_formulas=flag)})
+        assert eng.cfg.inline_formulas is flag and loaded[0] == want and "crnn.safetensors" in loaded
+    (tmp_path / "dbnet_inline.safetensors").unlink()
+    loaded.clear()
+    workers.build_engine("cpu", {"model": "full", "weights_dir": str(tmp_path), "cfg": dict(inline_formulas=True)})
+    assert loaded[0] == "dbnet.safetensors"
