@@ -38,7 +38,7 @@ from ..ops import dbpost
 from ..ops import jpeg as jpeg_ops
 from ..ops import lstm as lstm_ops
 from ..ops import resample as rs
-from ..utils.scripts import resolve_scripts, script_counts
+from ..utils.scripts import line_script, resolve_scripts, script_counts
 from . import layout
 
 
@@ -1062,12 +1062,17 @@ class OcrEngine:
             r = PageResult(p.doc_id, p.page_index, p.hw[1], p.hw[0],
                            n_detected=n_det, used_layout_prior=used_prior, error=rb.det.page_errors.get(pi))
             cur = None                  # the line whose pieces (text, formula, text, ...) are being put together
+            weak = False                # ... has a formula without a subscript, superscript, root or function call
             for k in range(b4.shape[0]):
                 gi = pos + k
+                if knd[k] in (KIND_TEXT, KIND_FORMULA, KIND_CELL, KIND_MATH_HEAD):
+                    weak = False
                 if knd[k] == KIND_LINE_ALT:
                     # the whole line read as text: taken when a formula cut out of it was read with little confidence
                     # (what the detector took for a formula was text), or when nothing else of the line was kept
-                    if ok[gi] and (cur is None or cur.formula_confidence < self.cfg.inline_min_conf):
+                    # ... or when the line is Greek prose and its "formulas" are Greek letters and operators only
+                    if ok[gi] and (cur is None or cur.formula_confidence < self.cfg.inline_min_conf or
+                                   (weak and line_script(texts[gi]) == "greek")):
                         alt = TextLine(tuple(float(v) for v in b4[k, :4]), texts[gi], float(confs[gi]), int(blk[k]),
                                        float(b4[k, 4]), "text")
                         if cur is None:
@@ -1089,6 +1094,8 @@ class OcrEngine:
                 piece = ("$" + texts[gi].strip() + "$" if texts[gi].strip() else "") if math else texts[gi]
                 if math and self.cfg.inline_needs_markup and not any(c in texts[gi] for c in "\\_^"):
                     confs[gi] = 0.0
+                if math and not any(c in texts[gi] for c in "_^("):
+                    weak = True
                 if knd[k] in (KIND_TEXT_CONT, KIND_MATH_CONT) and cur is not None:
                     if piece:
                         cur.text = (cur.text + " " + piece).strip()
