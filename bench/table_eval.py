@@ -1,6 +1,7 @@
 """Tables through the engine: how many synthetic table pages come back with exactly one table of the right shape, the
 character error rate of its cells, and how many pages show a figure that is not there
-(``python bench/table_eval.py [WEIGHTS_DIR] [N_PAGES]``)."""
+(``python bench/table_eval.py [WEIGHTS_DIR] [N_PAGES] [WRAP]``; WRAP: share of the body rows whose label runs onto a
+second line, 0 by default)."""
 import json
 import os
 import sys
@@ -17,6 +18,7 @@ from distributed_llms_amd.train.trainer import _edit_distance
 
 wd = sys.argv[1] if len(sys.argv) > 1 else "weights"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 48
+wrap = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
 eng = build_engine("cuda:0", {"model": "full", "weights_dir": wd, "cfg": dict(max_batch_pages=4)})
 fonts = [f for f in synth.available_fonts(synth.HELD_OUT_FONTS) if f.startswith("Lato")] + ["DejaVuSans.ttf", "DejaVuSerif.ttf"]
 rng = np.random.default_rng(7)
@@ -26,7 +28,7 @@ for k in range(n):
     kw = dict(rows=int(rng.integers(3, 12)), cols=int(rng.integers(2, 4 if column else 6)), ruled=bool(k % 2 == 0),
               row_pitch=float(rng.uniform(1.35, 2.3)), column=column, font_name=fonts[k % len(fonts)],
               font_px=int(rng.integers(30, 46)))
-    pg, tr, grid = synth.render_table_page(70_000 + k, **kw)
+    pg, tr, grid = synth.render_table_page(70_000 + k, wrap=wrap, **kw)
     cases.append((kw, grid))
     pages.append(pg)
 res = eng.process_pages([PageImage(torch.from_numpy(pg).pin_memory(), "e", k) for k, pg in enumerate(pages)])
@@ -53,6 +55,8 @@ for (kw, grid), r in zip(cases, res):
         bad.append({**kw, "got_shape": [len(cells), max(len(a) for a in cells)]})
 for o in out.values():
     o["cell_cer"] = round(o.pop("ed") / max(o.pop("ch"), 1), 4)
+if wrap > 0:
+    out["wrapped_label_share"] = wrap
 print(json.dumps(out))
 for b in bad[:12]:
     print(json.dumps(b))

@@ -93,6 +93,7 @@ struct Cutter {
   // of all rows falling into common columns (the whitespace between the columns runs through every row, at least 0.6
   // line heights wide), no row with two cells in one column, every column filled in at least half of the rows, and at
   // most one column of long text (two columns of running text whose lines happen to share baselines are not a table).
+  // Cells may wrap: a row of fewer boxes at line spacing under a table row (``continues_row``) belongs to that row.
   // Column boundaries of a would-be table: the middles of the x-intervals, at least 0.6 line heights wide, that at
   // most ``tol`` cells reach into (one over-long cell that runs up to its neighbour must not glue two columns of an
   // eight-row table together), with cells on both sides.
@@ -127,29 +128,82 @@ struct Cutter {
     if ((int)idx.size() < 2 * min_rows) return false;
     for (int i : idx) if (b[i].y1 - b[i].y0 > 3.0 * h_med) return false;     // a figure or a rotated line: no cell
     auto rows = rows_of(idx);
-    if ((int)rows.size() < min_rows) return false;
-    for (auto& r : rows) if (r.size() < 2) return false;
-    std::vector<double> cuts = table_cuts(idx, rows.size() >= 6 ? 1 : 0);
+    int n_full = 0;
+    for (auto& r : rows) n_full += r.size() >= 2;
+    if (n_full < min_rows || rows[0].size() < 2) return false;
+    std::vector<double> cuts = table_cuts(idx, n_full >= 6 ? 1 : 0);
     if (cuts.empty()) return false;
     const size_t C = cuts.size() + 1;
     std::vector<int> filled(C, 0);
     std::vector<std::vector<double>> aspect(C);
-    for (auto& r : rows) {
+    int n_rows = 0;
+    std::vector<char> base_cols(C, 0);
+    size_t base_size = 0;
+    // the white between two complete rows that follow each other: the lines of one cell are closer than that
+    size_t most = 0;
+    for (auto& r : rows) most = std::max(most, r.size());
+    std::vector<double> row_gaps;
+    for (size_t k = 1; k < rows.size(); ++k)
+      if (rows[k].size() == most && rows[k - 1].size() == most) row_gaps.push_back(row_gap(rows[k], rows[k - 1]));
+    const bool has_ref = !row_gaps.empty();
+    const double ref_gap = has_ref ? median(row_gaps) : 0.0;
+    for (size_t k = 0; k < rows.size(); ++k) {
+      auto& r = rows[k];
       std::vector<char> seen(C, 0);
+      std::vector<size_t> col;
       for (int i : r) {
         const size_t c = std::lower_bound(cuts.begin(), cuts.end(), b[i].x0 + 1e-6) - cuts.begin();
         if (seen[c]) return false;
         seen[c] = 1;
-        ++filled[c];
-        aspect[c].push_back((b[i].x1 - b[i].x0) / std::max(b[i].y1 - b[i].y0, 1.0));
+        col.push_back(c);
+      }
+      // the second (third ...) line of cells that wrap: part of the row above, no row of its own
+      const bool cont = k > 0 && continues_row(r, rows[k - 1], col, base_cols, base_size, cuts, has_ref, ref_gap);
+      if (!cont) {
+        if (r.size() < 2) return false;
+        ++n_rows;
+        base_cols = seen;
+        base_size = r.size();
+      }
+      for (size_t t = 0; t < r.size(); ++t) {
+        const int i = r[t];
+        if (!cont) ++filled[col[t]];
+        aspect[col[t]].push_back((b[i].x1 - b[i].x0) / std::max(b[i].y1 - b[i].y0, 1.0));
       }
     }
+    if (n_rows < min_rows) return false;
     int wide = 0;
     for (size_t c = 0; c < C; ++c) {
-      if (2 * filled[c] < (int)rows.size()) return false;
+      if (2 * filled[c] < n_rows) return false;
       if (median(aspect[c]) >= 10.0) ++wide;
     }
     return wide <= 1;
+  }
+
+  // White between a row and the row above it (negative when their boxes overlap).
+  double row_gap(const std::vector<int>& r, const std::vector<int>& above) const {
+    double top = 1e300, bottom = -1e300;
+    for (int i : r) top = std::min(top, b[i].y0);
+    for (int i : above) bottom = std::max(bottom, b[i].y1);
+    return top - bottom;
+  }
+
+  // Is row ``r`` the next line of cells of the table row above it that wrap?  It has fewer boxes than that row has
+  // cells, each in a column the row has a cell in and none reaching over a column boundary, and it follows the line
+  // above (``above``) at line spacing: less than three quarters of the white between two complete rows of this table
+  // (``ref_gap``) and at most a line height; at most 0.6 line heights where the table has no two complete rows in a
+  // row to compare with.
+  bool continues_row(const std::vector<int>& r, const std::vector<int>& above, const std::vector<size_t>& col,
+                     const std::vector<char>& base_cols, size_t base_size, const std::vector<double>& cuts,
+                     bool has_ref, double ref_gap) const {
+    if (r.size() >= base_size || base_size == 0) return false;
+    const double gap = row_gap(r, above);
+    if (gap > (has_ref ? 1.0 : 0.6) * h_med || (has_ref && gap >= 0.75 * ref_gap)) return false;
+    for (size_t t = 0; t < r.size(); ++t) {
+      if (!base_cols[col[t]]) return false;
+      if (col[t] < cuts.size() && b[r[t]].x1 > cuts[col[t]] + 0.1 * h_med) return false;
+    }
+    return true;
   }
 
   void leaf(const std::vector<int>& idx, bool table = false) {
@@ -284,19 +338,31 @@ struct Cutter {
     while (i < rows.size()) {
       auto multi = [&](size_t r) { return rows[r].second - rows[r].first >= 2; };
       if (!multi(i)) { ++i; continue; }
+      auto follows = [&](size_t r, double lim) {
+        return b[order[rows[r].first]].y0 - b[order[rows[r - 1].first]].y1 <= lim * h_med &&
+               cy(order[rows[r].first]) > cy(order[rows[r - 1].first]);
+      };
       size_t j = i + 1;
-      while (j < rows.size() && multi(j) &&
-             b[order[rows[j].first]].y0 - b[order[rows[j - 1].first]].y1 <= 3.0 * h_med &&
-             cy(order[rows[j].first]) > cy(order[rows[j - 1].first]))
-        ++j;
-      bool all_table = true;
-      for (size_t k = rows[i].first; k < rows[j - 1].second; ++k) all_table &= table_block[block_of[order[k]]] != 0;
-      if (j - i >= 3 && !all_table) {
-        std::vector<int> cells(order.begin() + rows[i].first, order.begin() + rows[j - 1].second);
+      while (j < rows.size() && multi(j) && follows(j, 3.0)) ++j;
+      // the same run with the further lines of wrapped cells (single boxes at line spacing) counted in; tried first,
+      // the run of complete rows alone after it
+      size_t e = i + 1;
+      int full = 1;
+      while (e < rows.size() && follows(e, multi(e) ? 3.0 : 1.0)) { full += multi(e); ++e; }
+      const std::pair<size_t, int> tries[2] = {{e, full}, {j, (int)(j - i)}};
+      for (int t = (e > j ? 0 : 1); t < 2; ++t) {
+        const size_t end = tries[t].first;
+        if (tries[t].second < 3) continue;
+        bool all_table = true;
+        for (size_t k = rows[i].first; k < rows[end - 1].second; ++k) all_table &= table_block[block_of[order[k]]] != 0;
+        if (all_table) continue;
+        std::vector<int> cells(order.begin() + rows[i].first, order.begin() + rows[end - 1].second);
         if (is_table(cells, 3)) {
           table_block.push_back(1);
           for (int c : cells) block_of[c] = n_blocks;
           ++n_blocks;
+          j = end;
+          break;
         }
       }
       i = j;
@@ -312,6 +378,17 @@ struct Cutter {
       if (rows[i].size() < 2) { ++i; continue; }
       size_t j = i;
       while (j < R && rows[j].size() >= 2) ++j;
+      // with the lines of wrapped cells between its rows a table is a longer run: rows of fewer boxes that follow the
+      // row above at line spacing count in (what comes of it is checked as a whole, then without them)
+      auto tight = [&](size_t e) { return row_gap(rows[e], rows[e - 1]) <= 1.0 * h_med; };
+      size_t e = i;
+      while (e < R && (rows[e].size() >= 2 || (e > i && tight(e)))) ++e;
+      if (e > j) {
+        int full = 0;
+        std::vector<int> cells;
+        for (size_t r = i; r < e; ++r) { full += rows[r].size() >= 2; cells.insert(cells.end(), rows[r].begin(), rows[r].end()); }
+        if (full >= 3 && is_table(cells, 3)) { tables.push_back({i, e}); i = e; continue; }
+      }
       if (j - i >= 3) {
         std::vector<int> cells;
         for (size_t r = i; r < j; ++r) cells.insert(cells.end(), rows[r].begin(), rows[r].end());

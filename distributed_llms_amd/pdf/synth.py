@@ -643,11 +643,13 @@ def render_layout_page(seed: int, size: Tuple[int, int] = A4_300DPI, layout: Opt
 
 def render_table_page(seed: int, size: Tuple[int, int] = A4_300DPI, rows: int = 5, cols: int = 3, ruled: bool = True,
                       row_pitch: float = 1.6, column: bool = False, font_name: str = "DejaVuSans.ttf",
-                      font_px: int = 38) -> Tuple[np.ndarray, PageTruth, List[List[str]]]:
+                      font_px: int = 38, wrap: float = 0.0) -> Tuple[np.ndarray, PageTruth, List[List[str]]]:
     """A page with two paragraphs and a ``rows`` x ``cols`` table between them (first column labels, the others
     numbers or short words; optional ruling lines; ``row_pitch`` line heights from row to row).  ``column``: the page
-    has two text columns and the table sits inside the left one.  The truth lists the lines in reading order with the
-    cells row by row; the third value is the grid of cell texts."""
+    has two text columns and the table sits inside the left one.  ``wrap``: that share of the body rows has a label
+    that runs onto a second line (at line spacing under the first; the row is a line taller).  The truth lists the
+    lines in reading order with the cells row by row (the second line of a label after its row); the third value is the
+    grid of cell texts."""
     W, H = size
     rng = np.random.default_rng(seed)
     scale = W / 2480.0
@@ -696,6 +698,11 @@ def render_table_page(seed: int, size: Tuple[int, int] = A4_300DPI, rows: int = 
             put(margin + c * cw + px // 2, y, t)
             row.append(t)
         grid.append(row)
+        if wrap > 0 and r > 0 and rng.random() < wrap:
+            t2 = (random_text(rng, 12) or "more")[: max(3, int((cw - 2.5 * px) / avg_char))].strip() or "more"
+            y += line_h
+            put(margin + px // 2, y, t2)
+            row[0] = row[0] + " " + t2
         if ruled:
             d.line([margin, y + int(line_h * row_pitch) - px // 3, margin + cols * cw, y + int(line_h * row_pitch) - px // 3], fill=90, width=max(1, px // 16))
         y += int(line_h * row_pitch)

@@ -112,20 +112,23 @@ def table_item(grid: Sequence[Sequence[str]], page_idx: int, bbox: Sequence[floa
 
 def table_grid(cells: Sequence[TextLine]) -> List[List[str]]:
     """Cells of one table (row by row, left to right, as the layout analysis orders them) -> rows x columns of text.
-    A new row starts where x stops growing.  The columns are bounded as the layout analysis bounds them
+    A new row starts where x stops growing or the line changes.  The columns are bounded as the layout analysis bounds them
     (``runtime/layout.py::table_cuts``): by the x-intervals, at least 0.6 line heights wide, that at most ``tol`` cells
     reach into - from six rows on one over-long cell may run up to its neighbour.  A cell belongs to the column its
-    left edge lies in; a row that lacks a cell gets an empty string there."""
+    left edge lies in; a row that lacks a cell gets an empty string there; the further lines of cells that wrap are joined
+    to the cell above them."""
     import bisect
 
     rows: List[List[TextLine]] = []
+    hs = sorted(c.box[3] - c.box[1] for c in cells)
     for c in cells:
-        if rows and c.box[0] > rows[-1][-1].box[0]:
+        first = rows[-1][0] if rows else None
+        if (first is not None and c.box[0] > rows[-1][-1].box[0] and
+                abs(0.5 * (c.box[1] + c.box[3]) - 0.5 * (first.box[1] + first.box[3])) <= 0.5 * hs[len(hs) // 2]):
             rows[-1].append(c)
         else:
             rows.append([c])
-    tol = 1 if len(rows) >= 6 else 0
-    hs = sorted(c.box[3] - c.box[1] for c in cells)
+    tol = 1 if sum(1 for r in rows if len(r) >= 2) >= 6 else 0
     min_gap = 0.6 * hs[len(hs) // 2]
     x0 = [c.box[0] for c in cells]
     x1 = [c.box[2] for c in cells]
@@ -140,13 +143,29 @@ def table_grid(cells: Sequence[TextLine]) -> List[List[str]]:
         if run is not None and run[1] - run[0] >= min_gap and any(q <= run[0] + 1e-9 for q in x1):
             cuts.append(0.5 * (run[0] + run[1]))
         run = None
-    grid = []
-    for r in rows:
-        out = [""] * (len(cuts) + 1)
-        for c in r:
-            k = bisect.bisect_right(cuts, c.box[0] + 1e-6)
+    grid: List[List[str]] = []
+    base_cols: set = set()
+    base_size = 0
+    h_med = hs[len(hs) // 2]
+    gap = lambda n: min(c.box[1] for c in rows[n]) - max(c.box[3] for c in rows[n - 1])      # noqa: E731
+    most = max(len(r) for r in rows)
+    full = sorted(gap(n) for n in range(1, len(rows)) if len(rows[n]) == most and len(rows[n - 1]) == most)
+    ref_gap = (full[len(full) // 2] if len(full) % 2 else 0.5 * (full[len(full) // 2 - 1] + full[len(full) // 2])) if full else None
+    for n, r in enumerate(rows):
+        cols = [bisect.bisect_right(cuts, c.box[0] + 1e-6) for c in r]
+        # the next line of cells that wrap (``runtime/layout.py::continues_row``): fewer boxes than the row has cells,
+        # all in columns the row has a cell in, at line spacing under the line above - joined to the cells above them
+        wraps = (grid and len(r) < base_size and set(cols) <= base_cols and
+                 gap(n) <= (1.0 if ref_gap is not None else 0.6) * h_med and (ref_gap is None or gap(n) < 0.75 * ref_gap) and
+                 all(k >= len(cuts) or c.box[2] <= cuts[k] + 0.1 * h_med for c, k in zip(r, cols)))
+        if wraps:
+            out = grid[-1]
+        else:
+            out = [""] * (len(cuts) + 1)
+            grid.append(out)
+            base_cols, base_size = set(cols), len(r)
+        for c, k in zip(r, cols):
             out[k] = (out[k] + " " + c.text.strip()).strip()
-        grid.append(out)
     return grid
 
 

@@ -119,32 +119,71 @@ class _Cutter:
         cells of all rows falling into common columns (the whitespace between the columns runs through every row - from
         six rows on, through all but one - at least 0.6 line heights wide), no row with two cells in one column, every column filled in at least half of the
         rows, and at most one column of long text (two columns of running text whose lines happen to share baselines
-        are not a table).  Cells that wrap onto a second line are not handled: such a region stays ordinary text."""
+        are not a table).  Cells may wrap: a row of fewer boxes at line spacing under a table row (``continues_row``)
+        belongs to that row."""
         b = self.b
         if idx.size < 2 * min_rows:
             return False
         if np.any(b[idx, 3] - b[idx, 1] > 3.0 * self.h_med):      # a figure or a rotated line: no cell
             return False
         rows = self.rows_of(idx)
-        if len(rows) < min_rows or any(r.size < 2 for r in rows):
+        n_full = sum(1 for r in rows if r.size >= 2)
+        if n_full < min_rows or rows[0].size < 2:
             return False
-        cuts = self.table_cuts(idx, 1 if len(rows) >= 6 else 0)
+        cuts = self.table_cuts(idx, 1 if n_full >= 6 else 0)
         if not cuts:
             return False
         C = len(cuts) + 1
         filled = [0] * C
         aspect: List[List[float]] = [[] for _ in range(C)]
         ca = np.asarray(cuts)
-        for r in rows:
+        n_rows = 0
+        base_cols: set = set()
+        base_size = 0
+        # the white between two complete rows that follow each other: the lines of one cell are closer than that
+        most = max(r.size for r in rows)
+        gaps = [float(b[rows[k], 1].min() - b[rows[k - 1], 3].max()) for k in range(1, len(rows))
+                if rows[k].size == most and rows[k - 1].size == most]
+        ref_gap = float(np.median(gaps)) if gaps else None
+        for k, r in enumerate(rows):
             col = np.searchsorted(ca, b[r, 0] + 1e-6)
             if np.unique(col).size != col.size:
                 return False
+            if k > 0 and self.continues_row(r, rows[k - 1], col, base_cols, base_size, ca, ref_gap):
+                # the second (third ...) line of cells that wrap: part of the row above, no row of its own
+                for i, c in zip(r, col):
+                    aspect[c].append(float((b[i, 2] - b[i, 0]) / max(b[i, 3] - b[i, 1], 1.0)))
+                continue
+            if r.size < 2:
+                return False
+            n_rows += 1
+            base_cols, base_size = set(int(c) for c in col), int(r.size)
             for i, c in zip(r, col):
                 filled[c] += 1
                 aspect[c].append(float((b[i, 2] - b[i, 0]) / max(b[i, 3] - b[i, 1], 1.0)))
-        if any(2 * f < len(rows) for f in filled):
+        if n_rows < min_rows or any(2 * f < n_rows for f in filled):
             return False
         return sum(1 for a in aspect if float(np.median(a)) >= 10.0) <= 1
+
+    def continues_row(self, r: np.ndarray, above: np.ndarray, col: np.ndarray, base_cols: set, base_size: int,
+                      cuts: np.ndarray, ref_gap: Optional[float]) -> bool:
+        """Is row ``r`` the next line of cells of the table row above it that wrap?  It has fewer boxes than that row
+        has cells, each in a column the row has a cell in and none reaching over a column boundary, and it follows the
+        line above (``above``) at line spacing: less than three quarters of the white between two complete rows of this
+        table (``ref_gap``) and at most a line height; at most 0.6 line heights where the table has no two complete rows
+        in a row to compare with."""
+        b = self.b
+        if r.size >= base_size or not base_cols:
+            return False
+        gap = float(b[r, 1].min() - b[above, 3].max())
+        if gap > (1.0 if ref_gap is not None else 0.6) * self.h_med or (ref_gap is not None and gap >= 0.75 * ref_gap):
+            return False
+        for i, c in zip(r, col):
+            if int(c) not in base_cols:
+                return False
+            if c < cuts.size and b[i, 2] > cuts[c] + 0.1 * self.h_med:
+                return False
+        return True
 
     def _is_text_column(self, idx: np.ndarray) -> bool:
         """A side of a vertical cut counts as a column of running text when it holds several lines that are much
@@ -228,8 +267,8 @@ class _Cutter:
     def tables_across_leaves(self) -> None:
         """Last pass over the finished reading sequence: rows of a table that the cuts left in different leaves (the
         first row glued to the paragraph above it, the others a block gap apart) are consecutive in the sequence all
-        the same.  Consecutive rows of two or more cells, at most three line heights from one to the next, that form a
-        grid become one table block of their own."""
+        the same.  Consecutive rows of two or more cells, at most three line heights from one to the next (with the
+        further lines of wrapped cells between them), that form a grid become one table block of their own."""
         b, order = self.b, self.order
         n = len(order)
         cy = lambda i: 0.5 * (b[i, 1] + b[i, 3])   # noqa: E731
@@ -243,17 +282,26 @@ class _Cutter:
             if rows[i][1] - rows[i][0] < 2:
                 i += 1
                 continue
+            follows = lambda j, lim: (b[order[rows[j][0]], 1] - b[order[rows[j - 1][0]], 3] <= lim * self.h_med    # noqa: E731
+                                      and cy(order[rows[j][0]]) > cy(order[rows[j - 1][0]]))
+            size = lambda j: rows[j][1] - rows[j][0]                                                               # noqa: E731
             j = i + 1
-            while (j < len(rows) and rows[j][1] - rows[j][0] >= 2
-                   and b[order[rows[j][0]], 1] - b[order[rows[j - 1][0]], 3] <= 3.0 * self.h_med
-                   and cy(order[rows[j][0]]) > cy(order[rows[j - 1][0]])):
+            while j < len(rows) and size(j) >= 2 and follows(j, 3.0):
                 j += 1
-            cells = np.asarray(order[rows[i][0] : rows[j - 1][1]], dtype=np.int64)
-            all_table = all(self.table_block[self.block_of[c]] for c in cells)
-            if j - i >= 3 and not all_table and self.is_table(cells, 3):
-                self.table_block.append(True)
-                self.block_of[cells] = self.n_blocks
-                self.n_blocks += 1
+            # the same run with the further lines of wrapped cells (single boxes at line spacing) counted in; tried
+            # first, the run of complete rows alone after it
+            e, full = i + 1, 1
+            while e < len(rows) and follows(e, 3.0 if size(e) >= 2 else 1.0):
+                full += size(e) >= 2
+                e += 1
+            for end, n_full in ((e, full), (j, j - i)) if e > j else ((j, j - i),):
+                cells = np.asarray(order[rows[i][0] : rows[end - 1][1]], dtype=np.int64)
+                if n_full >= 3 and not all(self.table_block[self.block_of[c]] for c in cells) and self.is_table(cells, 3):
+                    self.table_block.append(True)
+                    self.block_of[cells] = self.n_blocks
+                    self.n_blocks += 1
+                    j = end
+                    break
             i = j
 
     def leaf_with_tables(self, idx: np.ndarray) -> None:
@@ -271,6 +319,16 @@ class _Cutter:
             j = i
             while j < R and rows[j].size >= 2:
                 j += 1
+            # with the lines of wrapped cells between its rows a table is a longer run: rows of fewer boxes that follow
+            # the row above at line spacing count in (what comes of it is checked as a whole, then without them)
+            e = i
+            while e < R and (rows[e].size >= 2 or (e > i and self.b[rows[e], 1].min() - self.b[rows[e - 1], 3].max()
+                                                   <= 1.0 * self.h_med)):
+                e += 1
+            if e > j and sum(1 for r in rows[i:e] if r.size >= 2) >= 3 and self.is_table(np.concatenate(rows[i:e]), 3):
+                tables.append((i, e))
+                i = e
+                continue
             if j - i >= 3 and self.is_table(np.concatenate(rows[i:j]), 3):
                 tables.append((i, j))
             i = j

@@ -398,3 +398,26 @@ def test_widest_gap_picks_the_word_space_not_a_letter_gap():
     prof[52:60] = 30
     assert widest_gap(prof, 30) in (27, 28)
     assert widest_gap(np.full(40, 240, np.uint8), 20) is None
+
+
+@pytest.mark.parametrize("kw", [dict(cols=3, rows=5), dict(column=True, cols=3, rows=6), dict(cols=4, rows=8, row_pitch=2.2),
+                                dict(column=True, cols=2, rows=9, row_pitch=1.4)])
+def test_table_cells_that_wrap_onto_a_second_line_join_the_cell_above(kw):
+    """Labels that run onto a second line (at line spacing under the first, the next row further down): the table is
+    still found as one table, in both implementations, the extra lines come in reading order after their row, and the
+    grid holds each wrapped label as ONE cell."""
+    from distributed_llms_amd.runtime.document import table_grid
+    from distributed_llms_amd.runtime.engine import TextLine
+
+    for seed in (711, 712, 713):
+        arr, tr, grid = synth.render_table_page(seed, wrap=0.5, **kw)
+        b = tr.boxes.copy()
+        b[:, 1] -= 6          # detector boxes are taller than the ink
+        b[:, 3] += 6
+        a, c = layout.order_page(b, float(arr.shape[0])), layout.order_page_native(b, float(arr.shape[0]))
+        assert all(np.array_equal(x, y) for x, y in zip(a, c))
+        order, block, kind = c
+        assert order.tolist() == list(range(len(tr.texts)))
+        cells = [TextLine(tuple(b[i]), tr.texts[i], 1.0, int(block[i]), 0.0, "cell") for i, k in zip(order, kind) if k == 2]
+        assert len(cells) > sum(len(r) for r in grid) or seed != 711          # (seed 711 wraps at least one label)
+        assert table_grid(cells) == grid, (seed, kw)
