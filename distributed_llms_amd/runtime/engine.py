@@ -178,8 +178,9 @@ class EngineConfig:
     inline_inset: float = 0.25
     # a display formula is 60-100 page pixels tall = 6-10 pixels of the 1/4-scale block map: smaller size floor
     frm_db: dbpost.DBPostConfig = field(default_factory=lambda: dbpost.DBPostConfig(
-        bin_thresh=0.5, box_thresh=0.5, unclip_ratio=0.0, min_size=1, max_components=1024, max_boxes=64, max_angle_deg=0.0))
-    # (min_size 1: the band that marks a formula inside a text line is three map pixels tall)
+        bin_thresh=0.5, box_thresh=0.5, unclip_ratio=0.0, min_size=2, max_components=1024, max_boxes=64, max_angle_deg=0.0))
+    # (with ``inline_formulas`` the engine lowers min_size to 1: the band that marks a formula inside a text line is three
+    # map pixels tall; without it such specks - the "9" of "Y<9" - are no formulas)
     formula_min_side_px: int = 16
     formula_max_tokens: int = 96
     max_formulas_per_page: int = 64
@@ -370,6 +371,10 @@ class OcrEngine:
                  cfg: Optional[EngineConfig] = None, seed: int = 0, formula_rec=None):   # rec: CRNN or TrOCR
         self.device = torch.device(device)
         self.cfg = cfg or EngineConfig()
+        if self.cfg.inline_formulas and self.cfg.frm_db.min_size > 1:
+            from dataclasses import replace
+
+            self.cfg.frm_db = replace(self.cfg.frm_db, min_size=1)
         self.on_gpu = self.device.type == "cuda"
         if det is None or rec is None:
             g = torch.random.get_rng_state()
