@@ -6,7 +6,9 @@ services/ocr_service/download_models_hf.py:51) that magic-pdf runs inside ``pipe
 module is the XY-cut: recursive whitespace cuts over the boxes of a page, the same code for detector boxes of a scan
 and for the text-line boxes the native PDF reader reports for a born-digital page.  Parity with the learned model
 on real documents is unpinned; the behaviours covered by tests are multi-column pages, full-width headings above
-columns, page headers / footers, figures inside a column, and label / value rows (which must NOT be cut).
+columns, page headers / footers, figures inside a column, label / value rows (which must NOT be cut), and tables:
+grids of aligned cells (alone on a page, inside a column, under a paragraph without a block gap, with one over-long
+cell, with cells that wrap onto further lines) read row by row as one block.
 
     order, block_of = reading_order(boxes)          # boxes [n, 4] x0, y0, x1, y1, y down
 

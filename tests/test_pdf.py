@@ -402,3 +402,33 @@ def test_flate_scan_with_png_predictors_decodes_like_the_plain_one():
             got = doc.decode_image(doc.main_image(0))
             assert np.array_equal(got, page), (page.ndim, predictor)
             doc.close()
+
+
+def test_synthetic_pages_with_formulas_inside_lines_keep_their_truth_consistent():
+    """``render_layout_page(inline=...)``: the truth text of a line with formulas is its parts joined by spaces, formulas
+    as $...$; every formula box lies inside its line's box, left to right as the parts say; pages without ``inline``
+    are drawn exactly as before."""
+    from distributed_llms_amd.pdf import synth
+
+    pg, tr = synth.render_layout_page(77, size=(1240, 1754), layout="single", inline=0.6, noise=0.0)
+    assert len(tr.line_parts) >= 5 and tr.inline.shape[0] == len(tr.inline_texts) == len(tr.inline_line) >= 5
+    for li, parts in tr.line_parts.items():
+        assert tr.texts[li] == " ".join(t if k == "t" else "$" + t + "$" for k, _, _, t in parts)
+        xs = [x for _, x0, x1, _ in parts for x in (x0, x1)]
+        assert xs == sorted(xs)
+        assert any(k == "t" for k, *_ in parts) and any(k == "m" for k, *_ in parts)
+    for box, li, latex in zip(tr.inline, tr.inline_line, tr.inline_texts):
+        lb = tr.boxes[li]
+        assert lb[0] - 1 <= box[0] < box[2] <= lb[2] + 1 and lb[1] - 1 <= box[1] < box[3] <= lb[3] + 1
+        assert "$" + latex + "$" in tr.texts[li]
+    # the formula is set on the text baseline: ink of the formula and of the words share rows
+    li = tr.inline_line[0]
+    fb = tr.inline[0].astype(int)
+    rows_formula = np.nonzero((pg[fb[1]:fb[3], fb[0]:fb[2]] < 128).any(1))[0] + fb[1]
+    lb = tr.boxes[li].astype(int)
+    assert rows_formula.size and lb[1] <= rows_formula.min() and rows_formula.max() <= lb[3]
+    a, _ = synth.render_layout_page(78, size=(620, 877), layout="two_col", formulas=0.4)
+    b, tb = synth.render_layout_page(78, size=(620, 877), layout="two_col", formulas=0.4, inline=0.0)
+    assert np.array_equal(a, b) and not tb.line_parts
+    r = synth.render_formula_baseline("x_{i}^{2} + \\alpha", 40)
+    assert r is not None and 0 < r[1] <= r[0].shape[0] + 2
