@@ -228,7 +228,7 @@ def deskewed_boxes(b4: np.ndarray, angles: np.ndarray, page_hw: Tuple[int, int])
     return np.stack([rx - hw, ry - hh, rx + hw, ry + hh], 1).astype(np.float32), a
 
 
-KIND_TEXT, KIND_FORMULA, KIND_CELL, KIND_TEXT_CONT, KIND_MATH_CONT, KIND_MATH_HEAD, KIND_LINE_ALT = 0, 1, 2, 3, 4, 5, 6
+KIND_TEXT, KIND_FORMULA, KIND_CELL, KIND_TEXT_CONT, KIND_MATH_CONT, KIND_MATH_HEAD, KIND_LINE_ALT, KIND_MATH_TEXT = range(8)
 _MATH_KINDS = (KIND_FORMULA, KIND_MATH_CONT, KIND_MATH_HEAD)
 
 
@@ -284,9 +284,10 @@ def assign_inline_formulas(lines: np.ndarray, q: np.ndarray, min_score: float = 
 def split_line_at_formulas(row: np.ndarray, spans, min_text: float = 0.45) -> np.ndarray:
     """One line row (x0, y0, x1, y1, score, block, angle, kind) -> its pieces left to right as rows of the same form:
     stretches of text (kind 0 for the first piece, 3 after it) and formulas (5 / 4).  A stretch of text shorter than
-    ``min_text`` line heights is a sliver between a formula and the line's end, not text.  The last row (kind 6) is the
-    whole line once more: read as plain text, it is what the line falls back to when a formula in it is read with
-    little confidence."""
+    ``min_text`` line heights is a sliver between a formula and the line's end, not text.  Every formula piece is
+    followed by the same box as kind 7 (read by the text recogniser: what the piece falls back to when the formula
+    reading does not count), and the last row (kind 6) is the whole line once more, read as plain text: what the line
+    falls back to when none of its formulas counts (``OcrEngine._join_pieces``)."""
     cx, cy = 0.5 * (row[0] + row[2]), 0.5 * (row[1] + row[3])
     w, h = row[2] - row[0], row[3] - row[1]
     c, sn = np.cos(row[6]), np.sin(row[6])
@@ -305,21 +306,26 @@ def split_line_at_formulas(row: np.ndarray, spans, min_text: float = 0.45) -> np
         cur = a1
     if hi - cur >= min_text * h:
         parts.append((cur, hi, False, row[4]))
-    out = np.zeros((len(parts) + 1, row.shape[0]), np.float32)
-    out[-1] = row
-    m, half = 0.5 * (lo + hi), 0.5 * (hi - lo)
-    out[-1, :4] = (cx + m * c - half, cy + m * sn - 0.5 * h, cx + m * c + half, cy + m * sn + 0.5 * h)
-    out[-1, 7] = KIND_LINE_ALT
+    out = []
     for k, (u, v, is_math, sc) in enumerate(parts):
         m, half = 0.5 * (u + v), 0.5 * (v - u)
         px, py = cx + m * c, cy + m * sn
-        out[k] = row
-        out[k, :5] = (px - half, py - 0.5 * h, px + half, py + 0.5 * h, sc)
+        piece = row.copy()
+        piece[:5] = (px - half, py - 0.5 * h, px + half, py + 0.5 * h, sc)
         if is_math:
-            out[k, 7] = KIND_MATH_HEAD if k == 0 else KIND_MATH_CONT
+            piece[7] = KIND_MATH_HEAD if k == 0 else KIND_MATH_CONT
+            out.append(piece)
+            piece = piece.copy()                     # the same crop for the text recogniser
+            piece[7] = KIND_MATH_TEXT
         else:
-            out[k, 7] = KIND_TEXT if k == 0 else KIND_TEXT_CONT
-    return out
+            piece[7] = KIND_TEXT if k == 0 else KIND_TEXT_CONT
+        out.append(piece)
+    whole = row.copy()
+    m, half = 0.5 * (lo + hi), 0.5 * (hi - lo)
+    whole[:4] = (cx + m * c - half, cy + m * sn - 0.5 * h, cx + m * c + half, cy + m * sn + 0.5 * h)
+    whole[7] = KIND_LINE_ALT
+    out.append(whole)
+    return np.asarray(out, np.float32).reshape(-1, row.shape[0])
 
 
 def widest_gap(profile: np.ndarray, centre: int, min_run: int = 3) -> Optional[int]:
@@ -1066,56 +1072,27 @@ class OcrEngine:
         for pi, (p, (n_det, used_prior, b4, blk, fg, knd)) in enumerate(zip(rb.det.pages, per_page)):
             r = PageResult(p.doc_id, p.page_index, p.hw[1], p.hw[0],
                            n_detected=n_det, used_layout_prior=used_prior, error=rb.det.page_errors.get(pi))
-            cur = None                  # the line whose pieces (text, formula, text, ...) are being put together
-            weak = False                # ... has a formula without a subscript, superscript, root or function call
-            for k in range(b4.shape[0]):
-                gi = pos + k
-                if knd[k] in (KIND_TEXT, KIND_FORMULA, KIND_CELL, KIND_MATH_HEAD):
-                    weak = False
-                if knd[k] == KIND_LINE_ALT:
-                    # the whole line read as text: taken when a formula cut out of it was read with little confidence
-                    # (what the detector took for a formula was text), or when nothing else of the line was kept
-                    # ... or when the line is Greek prose and its "formulas" are Greek letters and operators only
-                    if ok[gi] and (cur is None or cur.formula_confidence < self.cfg.inline_min_conf or
-                                   (weak and line_script(texts[gi]) == "greek")):
-                        alt = TextLine(tuple(float(v) for v in b4[k, :4]), texts[gi], float(confs[gi]), int(blk[k]),
-                                       float(b4[k, 4]), "text")
-                        if cur is None:
-                            r.lines.append(alt)
-                        else:
-                            r.lines[-1] = alt
-                    cur = None
-                    continue
-                if knd[k] == KIND_FORMULA:
-                    cur = None
-                    r.lines.append(TextLine(tuple(float(v) for v in b4[k, :4]), texts[gi], float(confs[gi]), int(blk[k]),
-                                            0.0, "equation"))
-                    continue
-                math = knd[k] in (KIND_MATH_CONT, KIND_MATH_HEAD)
-                if not (math or ok[gi]):
-                    if knd[k] not in (KIND_TEXT_CONT, KIND_MATH_CONT):
-                        cur = None
-                    continue
-                piece = ("$" + texts[gi].strip() + "$" if texts[gi].strip() else "") if math else texts[gi]
-                if math and self.cfg.inline_needs_markup and not any(c in texts[gi] for c in "\\_^"):
-                    confs[gi] = 0.0
-                if math and not any(c in texts[gi] for c in "_^("):
-                    weak = True
-                if knd[k] in (KIND_TEXT_CONT, KIND_MATH_CONT) and cur is not None:
-                    if piece:
-                        cur.text = (cur.text + " " + piece).strip()
-                    bb = b4[k, :4]
-                    cur.box = (min(cur.box[0], float(bb[0])), min(cur.box[1], float(bb[1])),
-                               max(cur.box[2], float(bb[2])), max(cur.box[3], float(bb[3])))
-                    cur.confidence = min(cur.confidence, float(confs[gi]))
-                    if math:
-                        cur.formula_confidence = min(cur.formula_confidence, float(confs[gi]))
-                    continue
-                cur = TextLine(tuple(float(v) for v in b4[k, :4]), piece, float(confs[gi]), int(blk[k]),
-                               float(b4[k, 4]), "cell" if knd[k] == KIND_CELL else "text")
-                if math:
-                    cur.formula_confidence = float(confs[gi])
-                r.lines.append(cur)
+            # rows of one line follow each other: its first piece, then the other pieces of a line cut at formulas
+            # (text, formula + the same crop read as text, ...) and the whole line once more
+            n_rows, k = b4.shape[0], 0
+            follow = (KIND_TEXT_CONT, KIND_MATH_CONT, KIND_MATH_TEXT, KIND_LINE_ALT)
+            while k < n_rows:
+                e = k + 1
+                while e < n_rows and knd[e] in follow:
+                    e += 1
+                if e == k + 1 and knd[k] in (KIND_TEXT, KIND_CELL, KIND_FORMULA):          # the ordinary case
+                    gi = pos + k
+                    if knd[k] == KIND_FORMULA:
+                        r.lines.append(TextLine(tuple(float(v) for v in b4[k, :4]), texts[gi], float(confs[gi]), int(blk[k]),
+                                                0.0, "equation"))
+                    elif ok[gi]:
+                        r.lines.append(TextLine(tuple(float(v) for v in b4[k, :4]), texts[gi], float(confs[gi]), int(blk[k]),
+                                                float(b4[k, 4]), "cell" if knd[k] == KIND_CELL else "text"))
+                else:
+                    line = self._join_pieces(range(k, e), pos, b4, blk, knd, ok, texts, confs)
+                    if line is not None:
+                        r.lines.append(line)
+                k = e
             for k in range(fg.shape[0]):
                 crop = rb.fig_crops.get((pi, k))
                 if crop is not None:
@@ -1127,6 +1104,57 @@ class OcrEngine:
             results.append(r)
         self.pages_done += len(results)
         return results
+
+    def _join_pieces(self, rows, pos, b4, blk, knd, ok, texts, confs) -> Optional[TextLine]:
+        """One text line from the pieces it was cut into at the formulas inside it.  A formula counts when it was read
+        with a mean token probability of at least ``inline_min_conf``, has a command, subscript or superscript
+        (``inline_needs_markup``: "x = 3", "(a)", "12" are read as well by the text recogniser, and such tokens of
+        ordinary prose are what the formula map fires on by mistake) and, in a line of Greek prose, more than Greek
+        letters and operators; one that does not is replaced by the same crop read as text.  When no formula of the
+        line counts, the line is taken as the text recogniser read it whole (no cuts, no seams)."""
+        cfg = self.cfg
+        alt = None
+        for k in rows:
+            if knd[k] == KIND_LINE_ALT and ok[pos + k]:
+                alt = TextLine(tuple(float(v) for v in b4[k, :4]), texts[pos + k], float(confs[pos + k]), int(blk[k]),
+                               float(b4[k, 4]), "text")
+        greek = alt is not None and line_script(alt.text) == "greek"
+        pieces, box, conf, fconf, n_math = [], None, 1.0, 1.0, 0
+        rows = list(rows)
+        for n, k in enumerate(rows):
+            gi = pos + k
+            if knd[k] in (KIND_LINE_ALT, KIND_MATH_TEXT):
+                continue
+            if knd[k] in (KIND_MATH_HEAD, KIND_MATH_CONT):
+                latex = texts[gi].strip()
+                counts = (bool(latex) and float(confs[gi]) >= cfg.inline_min_conf and
+                          (not cfg.inline_needs_markup or any(c in latex for c in "\\_^")) and
+                          not (greek and not any(c in latex for c in "_^(")))
+                if counts:
+                    piece, used = "$" + latex + "$", float(confs[gi])
+                    n_math += 1
+                    fconf = min(fconf, used)
+                else:
+                    nxt = rows[n + 1] if n + 1 < len(rows) else -1
+                    if nxt < 0 or knd[nxt] != KIND_MATH_TEXT or not ok[pos + nxt]:
+                        continue
+                    piece, used = texts[pos + nxt], float(confs[pos + nxt])
+            elif ok[gi]:
+                piece, used = texts[gi], float(confs[gi])
+            else:
+                continue
+            if piece:
+                pieces.append(piece)
+            conf = min(conf, used)
+            bb = b4[k, :4]
+            box = tuple(float(v) for v in bb) if box is None else (min(box[0], float(bb[0])), min(box[1], float(bb[1])),
+                                                                  max(box[2], float(bb[2])), max(box[3], float(bb[3])))
+        if (n_math == 0 and alt is not None) or box is None:
+            return alt
+        k0 = rows[0]
+        line = TextLine(box, " ".join(pieces), conf, int(blk[k0]), float(b4[k0, 4]), "text")
+        line.formula_confidence = fconf
+        return line
 
     def _strings(self, ids: torch.Tensor, lens: torch.Tensor) -> List[str]:
         if self._lut is None:

@@ -360,15 +360,17 @@ def test_inline_assignment_and_split_follow_a_skewed_line():
     spans, taken = E.assign_inline_formulas(line, q)
     assert taken.tolist() == [True, False] and abs(spans[0][0][0] - 520) < 1 and abs(spans[0][0][1] - 680) < 1
     parts = E.split_line_at_formulas(line[0], spans[0])
-    assert parts[:, 7].tolist() == [E.KIND_TEXT, E.KIND_MATH_CONT, E.KIND_TEXT_CONT, E.KIND_LINE_ALT]
+    assert parts[:, 7].tolist() == [E.KIND_TEXT, E.KIND_MATH_CONT, E.KIND_MATH_TEXT, E.KIND_TEXT_CONT, E.KIND_LINE_ALT]
     assert np.array_equal(parts[-1, :7], line[0, :7])                      # the whole line once more, as the fallback
-    parts = parts[:-1]
+    assert np.array_equal(parts[2, :7], parts[1, :7])                      # the formula's crop, for the text recogniser
+    parts = parts[[0, 1, 3]]
     mid = 0.5 * (parts[1, :2] + parts[1, 2:4])
     assert np.allclose(mid, [1000 + a * np.cos(th), 530 + a * np.sin(th)], atol=0.5)
     assert np.allclose(parts[:, 3] - parts[:, 1], 60) and abs((parts[:, 2] - parts[:, 0]).sum() - 1800) < 1e-3
     # a line that begins with the formula; a sliver of text at the end is dropped
     parts = E.split_line_at_formulas(line[0], [(-900.0, -700.0, 0.7), (700.0, 885.0, 0.6)])
-    assert parts[:, 7].tolist() == [E.KIND_MATH_HEAD, E.KIND_TEXT_CONT, E.KIND_MATH_CONT, E.KIND_LINE_ALT]
+    assert parts[:, 7].tolist() == [E.KIND_MATH_HEAD, E.KIND_MATH_TEXT, E.KIND_TEXT_CONT, E.KIND_MATH_CONT, E.KIND_MATH_TEXT,
+                                    E.KIND_LINE_ALT]
 
 
 def test_a_formula_just_beyond_a_lines_end_joins_that_line():
@@ -381,8 +383,9 @@ def test_a_formula_just_beyond_a_lines_end_joins_that_line():
     spans, taken = E.assign_inline_formulas(line, q)
     assert taken.tolist() == [True, True, False]                 # the third lies a line further down: a display formula
     parts = E.split_line_at_formulas(line[0], spans[0])
-    assert parts[:, 7].tolist() == [E.KIND_MATH_HEAD, E.KIND_TEXT_CONT, E.KIND_MATH_CONT, E.KIND_LINE_ALT]
-    assert parts[:, 0].tolist() == [150, 380, 1930, 150] and parts[:, 2].tolist() == [380, 1930, 2100, 2100]
+    assert parts[:, 7].tolist() == [E.KIND_MATH_HEAD, E.KIND_MATH_TEXT, E.KIND_TEXT_CONT, E.KIND_MATH_CONT, E.KIND_MATH_TEXT,
+                                    E.KIND_LINE_ALT]
+    assert parts[:, 0].tolist() == [150, 150, 380, 1930, 1930, 150] and parts[:, 2].tolist() == [380, 380, 1930, 2100, 2100, 2100]
     # the pieces of a display formula that the text detector reports lie inside the formula's box: they do not claim it
     piece = np.array([[500, 1010, 700, 1060, 0.9, 0, 0.0, 0]], np.float32)
     spans, taken = E.assign_inline_formulas(piece, np.array([[400, 1000, 900, 1070, 0.9]], np.float32))
@@ -421,3 +424,35 @@ def test_table_cells_that_wrap_onto_a_second_line_join_the_cell_above(kw):
         cells = [TextLine(tuple(b[i]), tr.texts[i], 1.0, int(block[i]), 0.0, "cell") for i, k in zip(order, kind) if k == 2]
         assert len(cells) > sum(len(r) for r in grid) or seed != 711          # (seed 711 wraps at least one label)
         assert table_grid(cells) == grid, (seed, kw)
+
+
+def test_a_formula_that_does_not_count_falls_back_alone_and_the_line_whole_when_none_counts():
+    """``OcrEngine._join_pieces``: of two formulas cut out of a line, the one read without any command, subscript or
+    superscript is replaced by the same crop read as text while the other stays ``$...$``; when neither counts the
+    line is what the text recogniser read whole; in a line of Greek prose a formula of Greek letters and operators
+    alone does not count."""
+    import types
+
+    from distributed_llms_amd.runtime import engine as E
+
+    line = np.array([100, 500, 1900, 560, 0.9, 3, 0.0, 0], np.float32)
+    rows = E.split_line_at_formulas(line, [(-600.0, -400.0, 0.8), (200.0, 450.0, 0.9)])
+    kinds = rows[:, 7].astype(int)
+    assert kinds.tolist() == [E.KIND_TEXT, E.KIND_MATH_CONT, E.KIND_MATH_TEXT, E.KIND_TEXT_CONT, E.KIND_MATH_CONT, E.KIND_MATH_TEXT,
+                              E.KIND_TEXT_CONT, E.KIND_LINE_ALT]
+    b4 = rows[:, [0, 1, 2, 3, 6]]
+    blk = rows[:, 5].astype(int)
+    ok = np.ones(len(rows), bool)
+    me = types.SimpleNamespace(cfg=E.EngineConfig(inline_formulas=True))
+    join = lambda texts, confs: E.OcrEngine._join_pieces(me, range(len(rows)), 0, b4, blk, kinds, ok, texts, np.asarray(confs, np.float32))   # noqa: E731
+    texts = ["we take", "x_{i}^{2}", "xi2", "and", "x = 3", "x=3", "as given", "we take xi2 and x=3 as given"]
+    got = join(texts, [0.9, 0.97, 0.5, 0.9, 0.99, 0.8, 0.9, 0.85])
+    assert got.text == "we take $x_{i}^{2}$ and x=3 as given" and got.kind == "text" and got.block == 3
+    assert abs(got.box[0] - 100) < 1e-3 and abs(got.box[2] - 1900) < 1e-3 and abs(got.formula_confidence - 0.97) < 1e-6
+    # the first formula read with little confidence as well: nothing counts, the whole line as read in one piece
+    got = join(texts, [0.9, 0.4, 0.5, 0.9, 0.99, 0.8, 0.9, 0.85])
+    assert got.text == "we take xi2 and x=3 as given" and got.formula_confidence == 1.0
+    # Greek prose: Greek letters and an operator are text there, a subscript still makes a formula
+    texts = ["το", "\\alpha \\cdot \\beta", "αβ", "και", "\\lambda_{i}", "λi", "είναι", "το αβ και λi είναι"]
+    got = join(texts, [0.9, 0.99, 0.9, 0.9, 0.99, 0.8, 0.9, 0.9])
+    assert got.text == "το αβ και $\\lambda_{i}$ είναι"
