@@ -332,6 +332,26 @@ def text_layer_page(doc: "reader.PdfDocument", i: int, document_id: str, include
     return pr
 
 
+LOW_CONFIDENCE = 0.90        # median line confidence of a page below which its text is flagged
+LOW_CONFIDENCE_MIN_LINES = 5
+
+
+def low_confidence_warning(page_number: int, confidences) -> Optional[str]:
+    """The recogniser reads Latin, Cyrillic and Greek.  A page in another script (or one too degraded to read) still
+    comes back as text - letters that look a little like the glyphs - but the recogniser is unsure of every line of
+    it: a page in a known script reads at a median line confidence of 0.98 - 0.99, Hebrew, Georgian or Armenian at
+    0.69 - 0.81.  The reference stack picks its recogniser by detected language (services/ocr_service/
+    download_models_hf.py:41); here such a page is flagged in the document's ``warnings`` instead of passing as read."""
+    c = np.asarray(confidences, dtype=np.float32).reshape(-1)
+    if c.size < LOW_CONFIDENCE_MIN_LINES:
+        return None
+    med = float(np.median(c))
+    if med >= LOW_CONFIDENCE:
+        return None
+    return (f"page {page_number}: text read with low confidence (median {med:.2f} over {c.size} lines): the page may be in a "
+            "script other than Latin, Cyrillic or Greek, or too degraded to read")
+
+
 def assemble_document(document_id: str, mode: str, pages: Sequence[PageResult], t0: Optional[float] = None,
                       image_writer=None) -> "DocumentResult":
     """Pages -> content list, markdown and combined text (ocr_service.py:223-248).  Figure crops are handed to the
@@ -339,6 +359,10 @@ def assemble_document(document_id: str, mode: str, pages: Sequence[PageResult], 
     res = DocumentResult(document_id, mode)
     res.pages = sorted(pages, key=lambda p: p.page_index)
     res.warnings = [f"page {p.page_index + 1}: {p.error}" for p in res.pages if getattr(p, "error", None)]
+    for p in res.pages:
+        w = low_confidence_warning(p.page_index + 1, [l.confidence for l in p.lines if l.kind in ("text", "cell")])
+        if w:
+            res.warnings.append(w)
     if image_writer is not None:
         write_figures(res.pages, document_id, image_writer)
     res.content_list, res.discarded = drop_running_lines(build_content_list(res.pages), len(res.pages))
@@ -406,6 +430,9 @@ def assemble_packed(document_id: str, mode: str, shards: Sequence, extra: Dict[i
         err = sh.page_error(k)
         if err:
             res.warnings.append(f"page {i + 1}: {err}")
+        w = low_confidence_warning(i + 1, sh.page_confidences(k))
+        if w:
+            res.warnings.append(w)
         paths: Dict[int, str] = {}
         f0 = int(sh.fig_off[k])
         for f in range(f0, int(sh.fig_off[k + 1])):

@@ -196,6 +196,12 @@ class PackedShard:
             return None
         return bytes(self._sec["err"]).decode("utf-8", "surrogatepass")[a:b]
 
+    def page_confidences(self, k: int) -> np.ndarray:
+        """Recogniser confidence of the text lines and table cells of page slot ``k`` (formulas left out)."""
+        a, e = int(self.line_off[k]), int(self.line_off[k + 1])
+        kd = np.asarray(self.kind[a:e])
+        return np.asarray(self.conf[a:e])[(kd == _LINE_KINDS.index("text")) | (kd == _LINE_KINDS.index("cell"))]
+
     def figure_png(self, f: int) -> bytes:
         o = self.png_off
         return bytes(self._sec["png"][int(o[f]) : int(o[f + 1])])

@@ -290,3 +290,26 @@ def test_formulas_inside_lines_with_the_inline_detector():
     assert n_lines > 100 and with_math <= 0.02 * n_lines, (with_math, n_lines)
     ev = evaluate_pages(eng, plain)
     assert ev["cer"] < 0.01, ev
+
+
+def test_a_page_in_a_script_the_recogniser_does_not_know_is_flagged(pipe):
+    """Georgian and Hebrew pages still come back as "text" (look-alike letters), but the recogniser is unsure of every
+    line: the document carries a low-confidence warning for the page.  A page in held-out Latin fonts carries none."""
+    from PIL import Image, ImageDraw
+
+    def page(words, seed):
+        rng = np.random.default_rng(seed)
+        img = Image.new("L", synth.A4_300DPI, 244)
+        d = ImageDraw.Draw(img)
+        f = synth.named_font("DejaVuSans.ttf", 42)
+        for k in range(18):
+            d.text((220, 220 + 67 * k), " ".join(words[int(rng.integers(len(words)))] for _ in range(9)), fill=30, font=f)
+        return np.asarray(img)
+
+    geo = "გამარჯობა მსოფლიო წიგნი დოკუმენტი გვერდი ცხრილი სურათი თავი ნაწილი დანართი ანგარიში თანხა თარიღი ნომერი".split()
+    heb = "שלום עולם ספר מסמך עמוד טבלה תמונה פרק סעיף נספח דוח סכום תאריך מספר חתימה חוזה חברה מנהל בקשה כתובת".split()
+    pg_ok, _ = synth.render_layout_page(515_151, fonts=synth.HELD_OUT_FONTS, layout="single", skew=1.0)
+    doc = pipe.process_pdf(synth.make_scanned_pdf([page(geo, 1), pg_ok, page(heb, 2)], codec="jpeg"), "scripts")
+    low = [w for w in doc.warnings if "low confidence" in w]
+    assert len(low) == 2 and low[0].startswith("page 1:") and low[1].startswith("page 3:"), doc.warnings
+    assert "script other than Latin, Cyrillic or Greek" in low[0]

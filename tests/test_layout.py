@@ -456,3 +456,21 @@ def test_a_formula_that_does_not_count_falls_back_alone_and_the_line_whole_when_
     texts = ["το", "\\alpha \\cdot \\beta", "αβ", "και", "\\lambda_{i}", "λi", "είναι", "το αβ και λi είναι"]
     got = join(texts, [0.9, 0.99, 0.9, 0.9, 0.99, 0.8, 0.9, 0.9])
     assert got.text == "το αβ και $\\lambda_{i}$ είναι"
+
+
+def test_low_confidence_pages_are_flagged_in_the_documents_warnings():
+    from distributed_llms_amd.runtime.document import assemble_document, low_confidence_warning
+    from distributed_llms_amd.runtime.engine import PageResult, TextLine
+
+    assert low_confidence_warning(3, [0.99, 0.98, 0.97, 0.99, 0.99, 0.5]) is None           # one bad line is no bad page
+    assert low_confidence_warning(3, [0.7, 0.75]) is None                                    # too few lines to tell
+    w = low_confidence_warning(3, [0.7, 0.75, 0.8, 0.72, 0.69, 0.81])
+    assert w.startswith("page 3:") and "0.73" in w or "0.74" in w
+
+    def page(i, conf):
+        p = PageResult("d", i, 1000, 1400)
+        p.lines = [TextLine((50, 100 + 40 * k, 900, 130 + 40 * k), f"line {k} of the page", conf, 0) for k in range(8)]
+        return p
+
+    doc = assemble_document("d", "ocr", [page(0, 0.99), page(1, 0.72)])
+    assert len(doc.warnings) == 1 and doc.warnings[0].startswith("page 2: text read with low confidence")
