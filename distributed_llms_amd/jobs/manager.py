@@ -115,7 +115,9 @@ class JobManager:
                 final = {"status": "completed", "document_hash": document_hash, "result": result["result"],
                          "completed_at": _now(), "owner": self.node_id}
                 if result.get("warnings"):
-                    final["warnings"] = result["warnings"]      # e.g. pages whose image stream was damaged
+                    final["warnings"] = result["warnings"]      # pages with a damaged image stream / read with low confidence
+                    for w in result["warnings"]:
+                        metrics.PAGE_WARNINGS.labels("low_confidence" if "low confidence" in w else "damaged").inc()
                 await self._io(self.status.update, document_id, final)
                 metrics.STAGE_SECONDS.labels("store").observe(time.perf_counter() - t1)
                 metrics.DOCUMENTS.labels("completed").inc()

@@ -9,6 +9,9 @@ REGISTRY = CollectorRegistry()
 
 DOCUMENTS = Counter("ocr_documents_total", "Documents finished, by outcome", ["outcome"], registry=REGISTRY)
 PAGES = Counter("ocr_pages_total", "Pages extracted", registry=REGISTRY)
+PAGE_WARNINGS = Counter("ocr_page_warnings_total", "Pages flagged in a completed document, by reason "
+                        "(damaged: image stream not decodable to the end; low_confidence: unknown script or unreadable scan)",
+                        ["reason"], registry=REGISTRY)
 REQUESTS = Counter("ocr_http_requests_total", "HTTP requests", ["route", "code"], registry=REGISTRY)
 JOBS_IN_FLIGHT = Gauge("ocr_jobs_in_flight", "Background extraction jobs running", registry=REGISTRY)
 QUEUE_DEPTH = Gauge("ocr_worker_queue_pages", "Pages queued per GPU worker", ["worker"], registry=REGISTRY)

@@ -389,3 +389,25 @@ def test_metrics_export_engine_stage_timers_and_worker_memory(ctx):
     assert 'ocr_gpu_memory_bytes{gpu="0",kind="reserved"} 9.663676416e+09' in text
     assert 'ocr_gpu_memory_bytes{gpu="1",kind="allocated"}' in text
     assert "ocr_batch_fill_ratio 0.75" in text
+
+
+def test_page_warnings_reach_the_status_record_and_the_metrics(ctx):
+    """A completed document whose pages were damaged or read with low confidence: the status record lists the warnings and
+    ``ocr_page_warnings_total`` counts them by reason."""
+    from distributed_llms_amd.utils import metrics
+
+    settings, status, results = ctx
+    warn = ["page 2: page image is damaged: 10 of 900 JPEG blocks could be decoded; no text is reported for this page",
+            "page 3: text read with low confidence (median 0.71 over 18 lines): the page may be in a script other than Latin, "
+            "Cyrillic or Greek, or too degraded to read"]
+    before = {r: metrics.PAGE_WARNINGS.labels(r)._value.get() for r in ("damaged", "low_confidence")}
+    app = create_app(settings, status, results, StubExtractor({"status": "completed", "result": "some text", "pages": 3,
+                                                                "warnings": warn}))
+    with TestClient(app) as c:
+        _post(c, b"%PDF-1.4 warn", "w1")
+        assert _wait(c, "w1") == "completed"
+        assert status.get("w1")["warnings"] == warn
+        text = c.get("/metrics").text
+        assert 'ocr_page_warnings_total{reason="low_confidence"}' in text and 'ocr_page_warnings_total{reason="damaged"}' in text
+    assert metrics.PAGE_WARNINGS.labels("damaged")._value.get() == before["damaged"] + 1
+    assert metrics.PAGE_WARNINGS.labels("low_confidence")._value.get() == before["low_confidence"] + 1
