@@ -307,6 +307,71 @@ static void inflate_stress() {
   printf("  inflate: round trips exact; %lld of %lld damaged / short-buffer streams refused, none overran\n", refused, total);
 }
 
+extern "C" int dlrt_layout_order(const float* boxes, int n, const float* figs, int nf, float page_h, int* order_out,
+                                 int* block_out, int* kind_out);
+
+// Layout analysis on pages it was not written for: text columns, grids of cells with wrapped lines and holes, and
+// boxes that make no sense (empty, inverted, huge, all equal, thousands of them).  Whatever comes in, the answer is a
+// permutation of the input with a block and a kind for every entry.
+static void layout_stress() {
+  std::mt19937 rng(11);
+  auto uni = [&](float a, float b) { return a + (b - a) * (float)(rng() % 100000) / 100000.f; };
+  long long pages = 0, cells = 0;
+  for (int it = 0; it < 600; ++it) {
+    std::vector<float> bx, fg;
+    auto put = [&](float x0, float y0, float x1, float y1) { bx.push_back(x0); bx.push_back(y0); bx.push_back(x1); bx.push_back(y1); };
+    const int mode = it % 6;
+    const float h = uni(20, 70);
+    if (mode == 0 || mode == 1) {                       // one or two text columns
+      const int ncol = 1 + mode;
+      for (int c = 0; c < ncol; ++c)
+        for (float y = 200; y < 3000; y += h * uni(1.3f, 1.8f))
+          put(200 + c * 1100, y, 200 + c * 1100 + uni(300, 1000), y + h);
+    } else if (mode == 2 || mode == 3) {                // a table under a paragraph: wrapped cells, missing cells
+      float y = 200;
+      for (int k = 0; k < 4; ++k, y += h * 1.5f) put(200, y, 2200, y + h);
+      const int cols = 2 + (int)(rng() % 4), rows = 3 + (int)(rng() % 9);
+      const float cw = 2000.f / cols, pitch = h * uni(1.3f, 2.6f);
+      for (int r = 0; r < rows; ++r) {
+        for (int c = 0; c < cols; ++c)
+          if (mode == 2 || rng() % 7) put(200 + c * cw + 10, y, 200 + c * cw + uni(40, cw - 30), y + h);
+        if (rng() % 3 == 0) { y += h * 1.25f; put(200 + 10, y, 200 + uni(40, cw - 30), y + h); }
+        y += pitch;
+      }
+      for (int k = 0; k < 3; ++k, y += h * 1.5f) put(200, y + h, 2200, y + 2 * h);
+    } else if (mode == 4) {                             // nonsense
+      const int n = (int)(rng() % 40);
+      for (int k = 0; k < n; ++k) {
+        const int w = (int)(rng() % 5);
+        if (w == 0) put(500, 500, 500, 500);
+        else if (w == 1) put(uni(0, 2000), uni(0, 3000), uni(0, 2000), uni(0, 3000));      // possibly inverted
+        else if (w == 2) put(-1e6f, -1e6f, 1e6f, 1e6f);
+        else if (w == 3) put(100, 100, 900, 140);                                          // many equal boxes
+        else put(uni(0, 2400), uni(0, 3400), uni(0, 2400) + 1e-3f, uni(0, 3400) + 1e-3f);
+      }
+    } else {                                            // many boxes
+      const int n = 2000 + (int)(rng() % 2000);
+      for (int k = 0; k < n; ++k) { const float x = uni(0, 2300), y = uni(0, 3400); put(x, y, x + uni(5, 300), y + uni(5, 60)); }
+    }
+    const int nf = (int)(rng() % 3);
+    for (int k = 0; k < nf; ++k) { const float x = uni(100, 1500), y = uni(100, 2500); fg.insert(fg.end(), {x, y, x + uni(50, 800), y + uni(50, 800)}); }
+    const int n = (int)bx.size() / 4;
+    std::vector<int> order(n + nf + 1, -7), block(n + nf + 1, -7), kind(n + nf + 1, -7);
+    const int got = dlrt_layout_order(bx.data(), n, nf ? fg.data() : nullptr, nf, 3508.f, order.data(), block.data(), kind.data());
+    if (got != n + nf) { fprintf(stderr, "layout: %d entries for %d boxes + %d figures\n", got, n, nf); exit(3); }
+    std::vector<char> seen(n + nf, 0);
+    for (int k = 0; k < got; ++k) {
+      if (order[k] < 0 || order[k] >= n + nf || seen[order[k]]) { fprintf(stderr, "layout: order is no permutation\n"); exit(3); }
+      seen[order[k]] = 1;
+      if (kind[k] < 0 || kind[k] > 2 || block[k] < 0) { fprintf(stderr, "layout: bad kind / block\n"); exit(3); }
+      cells += kind[k] == 2;
+    }
+    if (order[got] != -7) { fprintf(stderr, "layout: wrote past the end\n"); exit(3); }
+    ++pages;
+  }
+  printf("  layout: %lld pages ordered, %lld table cells, every answer a permutation\n", pages, cells);
+}
+
 int main(int argc, char** argv) {
   int iters = 1500;
   for (int i = 1; i < argc; ++i) {
@@ -324,6 +389,7 @@ int main(int argc, char** argv) {
   inflate_stress();
   batcher_stress();
   bpe_stress();
+  layout_stress();
   printf("sanitize: OK\n");
   return 0;
 }

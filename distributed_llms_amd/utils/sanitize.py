@@ -1,9 +1,10 @@
 """Debug build target: host C++ under AddressSanitizer + UBSan.
 
-Builds ``csrc/tests/sanitize_main.cpp`` together with the PDF reader, batcher and BPE sources into
+Builds ``csrc/tests/sanitize_main.cpp`` together with the PDF reader, batcher, BPE and layout-analysis sources into
 ``build/sanitize/dlamd_san`` (``-fsanitize=address,undefined``, runtimes linked statically so a preloaded
 library cannot displace them) and runs it on freshly generated text / scanned PDFs plus thousands of
-mutated copies.  GPU code is not covered: device-side sanitizers are unavailable on this pool, the HIP
+mutated copies, and the layout analysis on generated pages (columns, tables with wrapped and missing cells) and on
+boxes that make no sense.  GPU code is not covered: device-side sanitizers are unavailable on this pool, the HIP
 kernels are guarded by host-side shape contracts and canary tests instead (tests/test_kernels_gpu.py).
 
     python -m distributed_llms_amd.utils.sanitize [--iters N]

@@ -1,4 +1,5 @@
-"""Host C++ (PDF reader, JPEG scanner, batcher, BPE vocabulary) under ASan + UBSan on mutated inputs."""
+"""Host C++ (PDF reader, JPEG scanner, inflater, batcher, BPE vocabulary, layout analysis) under ASan + UBSan on mutated
+and nonsensical inputs."""
 import shutil
 
 import pytest
