@@ -139,26 +139,30 @@ struct Cutter {
     int n_rows = 0;
     std::vector<char> base_cols(C, 0);
     size_t base_size = 0;
-    // the white between two complete rows that follow each other: the lines of one cell are closer than that
+    // the white between the cells of two complete rows that follow each other, column by column: the lines of one cell
+    // are closer than that (in two columns of short lines that merely share some baselines they are not)
     size_t most = 0;
     for (auto& r : rows) most = std::max(most, r.size());
+    std::vector<std::vector<size_t>> cols_of(rows.size());
+    for (size_t k = 0; k < rows.size(); ++k)
+      for (int i : rows[k]) cols_of[k].push_back(std::lower_bound(cuts.begin(), cuts.end(), b[i].x0 + 1e-6) - cuts.begin());
     std::vector<double> row_gaps;
     for (size_t k = 1; k < rows.size(); ++k)
-      if (rows[k].size() == most && rows[k - 1].size() == most) row_gaps.push_back(row_gap(rows[k], rows[k - 1]));
+      if (rows[k].size() == most && rows[k - 1].size() == most && cols_of[k] == cols_of[k - 1])
+        for (size_t t = 0; t < rows[k].size(); ++t) row_gaps.push_back(b[rows[k][t]].y0 - b[rows[k - 1][t]].y1);
     const bool has_ref = !row_gaps.empty();
     const double ref_gap = has_ref ? median(row_gaps) : 0.0;
+    std::vector<double> bottom(C, 0.0);                  // lower edge of the last box seen in each column
     for (size_t k = 0; k < rows.size(); ++k) {
       auto& r = rows[k];
+      const auto& col = cols_of[k];
       std::vector<char> seen(C, 0);
-      std::vector<size_t> col;
-      for (int i : r) {
-        const size_t c = std::lower_bound(cuts.begin(), cuts.end(), b[i].x0 + 1e-6) - cuts.begin();
+      for (size_t c : col) {
         if (seen[c]) return false;
         seen[c] = 1;
-        col.push_back(c);
       }
       // the second (third ...) line of cells that wrap: part of the row above, no row of its own
-      const bool cont = k > 0 && continues_row(r, rows[k - 1], col, base_cols, base_size, cuts, has_ref, ref_gap);
+      const bool cont = k > 0 && continues_row(r, col, bottom, base_cols, base_size, cuts, has_ref, ref_gap);
       if (!cont) {
         if (r.size() < 2) return false;
         ++n_rows;
@@ -169,6 +173,7 @@ struct Cutter {
         const int i = r[t];
         if (!cont) ++filled[col[t]];
         aspect[col[t]].push_back((b[i].x1 - b[i].x0) / std::max(b[i].y1 - b[i].y0, 1.0));
+        bottom[col[t]] = b[i].y1;
       }
     }
     if (n_rows < min_rows) return false;
@@ -189,19 +194,19 @@ struct Cutter {
   }
 
   // Is row ``r`` the next line of cells of the table row above it that wrap?  It has fewer boxes than that row has
-  // cells, each in a column the row has a cell in and none reaching over a column boundary, and it follows the line
-  // above (``above``) at line spacing: less than three quarters of the white between two complete rows of this table
-  // (``ref_gap``) and at most a line height; at most 0.6 line heights where the table has no two complete rows in a
-  // row to compare with.
-  bool continues_row(const std::vector<int>& r, const std::vector<int>& above, const std::vector<size_t>& col,
+  // cells, each in a column the row has a cell in and none reaching over a column boundary, and each follows the box
+  // above it in its column (``bottom``) at line spacing: less than three quarters of the white between the cells of
+  // two complete rows of this table (``ref_gap``) and at most a line height; at most 0.6 line heights where the table
+  // has no two complete rows in a row to compare with.
+  bool continues_row(const std::vector<int>& r, const std::vector<size_t>& col, const std::vector<double>& bottom,
                      const std::vector<char>& base_cols, size_t base_size, const std::vector<double>& cuts,
                      bool has_ref, double ref_gap) const {
     if (r.size() >= base_size || base_size == 0) return false;
-    const double gap = row_gap(r, above);
-    if (gap > (has_ref ? 1.0 : 0.6) * h_med || (has_ref && gap >= 0.75 * ref_gap)) return false;
     for (size_t t = 0; t < r.size(); ++t) {
       if (!base_cols[col[t]]) return false;
       if (col[t] < cuts.size() && b[r[t]].x1 > cuts[col[t]] + 0.1 * h_med) return false;
+      const double gap = b[r[t]].y0 - bottom[col[t]];
+      if (gap > (has_ref ? 1.0 : 0.6) * h_med || (has_ref && gap >= 0.75 * ref_gap)) return false;
     }
     return true;
   }

@@ -147,17 +147,21 @@ def table_grid(cells: Sequence[TextLine]) -> List[List[str]]:
     base_cols: set = set()
     base_size = 0
     h_med = hs[len(hs) // 2]
-    gap = lambda n: min(c.box[1] for c in rows[n]) - max(c.box[3] for c in rows[n - 1])      # noqa: E731
+    cols_of = [[bisect.bisect_right(cuts, c.box[0] + 1e-6) for c in r] for r in rows]
     most = max(len(r) for r in rows)
-    full = sorted(gap(n) for n in range(1, len(rows)) if len(rows[n]) == most and len(rows[n - 1]) == most)
+    full = sorted(c.box[1] - a.box[3] for n in range(1, len(rows))
+                  if len(rows[n]) == most and len(rows[n - 1]) == most and cols_of[n] == cols_of[n - 1]
+                  for a, c in zip(rows[n - 1], rows[n]))
     ref_gap = (full[len(full) // 2] if len(full) % 2 else 0.5 * (full[len(full) // 2 - 1] + full[len(full) // 2])) if full else None
+    limit = (1.0 if ref_gap is not None else 0.6) * h_med
+    bottom = [0.0] * (len(cuts) + 1)             # lower edge of the last box seen in each column
     for n, r in enumerate(rows):
-        cols = [bisect.bisect_right(cuts, c.box[0] + 1e-6) for c in r]
+        cols = cols_of[n]
         # the next line of cells that wrap (``runtime/layout.py::continues_row``): fewer boxes than the row has cells,
-        # all in columns the row has a cell in, at line spacing under the line above - joined to the cells above them
+        # all in columns the row has a cell in, each at line spacing under the box above it - joined to the cells above
         wraps = (grid and len(r) < base_size and set(cols) <= base_cols and
-                 gap(n) <= (1.0 if ref_gap is not None else 0.6) * h_med and (ref_gap is None or gap(n) < 0.75 * ref_gap) and
-                 all(k >= len(cuts) or c.box[2] <= cuts[k] + 0.1 * h_med for c, k in zip(r, cols)))
+                 all(c.box[1] - bottom[k] <= limit and (ref_gap is None or c.box[1] - bottom[k] < 0.75 * ref_gap) and
+                     (k >= len(cuts) or c.box[2] <= cuts[k] + 0.1 * h_med) for c, k in zip(r, cols)))
         if wraps:
             out = grid[-1]
         else:
@@ -166,6 +170,7 @@ def table_grid(cells: Sequence[TextLine]) -> List[List[str]]:
             base_cols, base_size = set(cols), len(r)
         for c, k in zip(r, cols):
             out[k] = (out[k] + " " + c.text.strip()).strip()
+            bottom[k] = c.box[3]
     return grid
 
 

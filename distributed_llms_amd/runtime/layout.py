@@ -142,19 +142,25 @@ class _Cutter:
         n_rows = 0
         base_cols: set = set()
         base_size = 0
-        # the white between two complete rows that follow each other: the lines of one cell are closer than that
+        # the white between the cells of two complete rows that follow each other, column by column: the lines of one
+        # cell are closer than that (in two columns of short lines that merely share some baselines they are not)
         most = max(r.size for r in rows)
-        gaps = [float(b[rows[k], 1].min() - b[rows[k - 1], 3].max()) for k in range(1, len(rows))
-                if rows[k].size == most and rows[k - 1].size == most]
+        cols_of = [np.searchsorted(ca, b[r, 0] + 1e-6) for r in rows]
+        gaps = []
+        for k in range(1, len(rows)):
+            if rows[k].size == most and rows[k - 1].size == most and np.array_equal(cols_of[k], cols_of[k - 1]):
+                gaps.extend((b[rows[k], 1] - b[rows[k - 1], 3]).tolist())
         ref_gap = float(np.median(gaps)) if gaps else None
+        bottom = [0.0] * C                     # lower edge of the last box seen in each column
         for k, r in enumerate(rows):
-            col = np.searchsorted(ca, b[r, 0] + 1e-6)
+            col = cols_of[k]
             if np.unique(col).size != col.size:
                 return False
-            if k > 0 and self.continues_row(r, rows[k - 1], col, base_cols, base_size, ca, ref_gap):
+            if k > 0 and self.continues_row(r, col, bottom, base_cols, base_size, ca, ref_gap):
                 # the second (third ...) line of cells that wrap: part of the row above, no row of its own
                 for i, c in zip(r, col):
                     aspect[c].append(float((b[i, 2] - b[i, 0]) / max(b[i, 3] - b[i, 1], 1.0)))
+                    bottom[c] = float(b[i, 3])
                 continue
             if r.size < 2:
                 return False
@@ -163,27 +169,28 @@ class _Cutter:
             for i, c in zip(r, col):
                 filled[c] += 1
                 aspect[c].append(float((b[i, 2] - b[i, 0]) / max(b[i, 3] - b[i, 1], 1.0)))
+                bottom[c] = float(b[i, 3])
         if n_rows < min_rows or any(2 * f < n_rows for f in filled):
             return False
         return sum(1 for a in aspect if float(np.median(a)) >= 10.0) <= 1
 
-    def continues_row(self, r: np.ndarray, above: np.ndarray, col: np.ndarray, base_cols: set, base_size: int,
+    def continues_row(self, r: np.ndarray, col: np.ndarray, bottom: List[float], base_cols: set, base_size: int,
                       cuts: np.ndarray, ref_gap: Optional[float]) -> bool:
         """Is row ``r`` the next line of cells of the table row above it that wrap?  It has fewer boxes than that row
-        has cells, each in a column the row has a cell in and none reaching over a column boundary, and it follows the
-        line above (``above``) at line spacing: less than three quarters of the white between two complete rows of this
-        table (``ref_gap``) and at most a line height; at most 0.6 line heights where the table has no two complete rows
-        in a row to compare with."""
+        has cells, each in a column the row has a cell in and none reaching over a column boundary, and each follows the
+        box above it in its column (``bottom``) at line spacing: less than three quarters of the white between the cells
+        of two complete rows of this table (``ref_gap``) and at most a line height; at most 0.6 line heights where the
+        table has no two complete rows in a row to compare with."""
         b = self.b
         if r.size >= base_size or not base_cols:
-            return False
-        gap = float(b[r, 1].min() - b[above, 3].max())
-        if gap > (1.0 if ref_gap is not None else 0.6) * self.h_med or (ref_gap is not None and gap >= 0.75 * ref_gap):
             return False
         for i, c in zip(r, col):
             if int(c) not in base_cols:
                 return False
             if c < cuts.size and b[i, 2] > cuts[c] + 0.1 * self.h_med:
+                return False
+            gap = float(b[i, 1]) - bottom[int(c)]
+            if gap > (1.0 if ref_gap is not None else 0.6) * self.h_med or (ref_gap is not None and gap >= 0.75 * ref_gap):
                 return False
         return True
 
