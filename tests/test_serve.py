@@ -208,3 +208,27 @@ def test_shared_worker_servers_behind_several_front_ends(tmp_path, monkeypatch):
         sup.shutdown()
     kids = [p.pid for p in sup.children.values()]
     assert not [n for n in os.listdir("/dev/shm") if any(n.startswith(f"dlamd-{k}-") for k in kids)], "segments left behind"
+
+
+def test_alert_rules_name_only_metrics_the_service_exports():
+    """deploy/observability/alerts.yml: every ``ocr_*`` series an alert reads is one ``utils/metrics.py`` registers, and the
+    scrape configuration loads the rule file."""
+    import re
+    from pathlib import Path
+
+    import yaml
+
+    from distributed_llms_amd.utils import metrics
+
+    root = Path(__file__).resolve().parents[1] / "deploy" / "observability"
+    rules = yaml.safe_load((root / "alerts.yml").read_text())["groups"][0]["rules"]
+    assert len(rules) >= 6 and all(r["alert"] and r["expr"] and r["annotations"]["summary"] for r in rules)
+    exported = set()
+    for fam in metrics.REGISTRY.collect():
+        exported.add(fam.name)
+        exported.update(s.name for s in fam.samples)
+        exported.add(fam.name + "_total")
+    for r in rules:
+        for name in re.findall(r"\bocr_[a-z_]+", r["expr"]):
+            assert name in exported, (r["alert"], name)
+    assert "alerts.yml" in yaml.safe_load((root / "prometheus.yml").read_text())["rule_files"]
