@@ -237,8 +237,9 @@ def assign_inline_formulas(lines: np.ndarray, q: np.ndarray, min_score: float = 
     rectangles (turned by ``angle`` about their centre; rows of NaN are skipped), ``q`` [m, >= 4] upright formula boxes.
     A formula box whose centre lies in a line's rectangle, with at least one line height of that line left over beside
     it, is part of the line (the text detector fires on the pieces of a display formula too, but those pieces end where
-    the formula ends).  A box inside a line whose mean probability is below ``min_score`` is set aside too (it is no
-    display formula) but cuts nothing out of its line.  -> ({line index: [(a0, a1, score)] along the line's axis
+    the formula ends).  So is a box on a line's baseline just beyond its end, up to 1.2 line heights away: a line that
+    begins or ends with a formula, which the text detector tends to leave out.  A box inside a line whose mean
+    probability is below ``min_score`` is set aside too (it is no display formula) but cuts nothing out of its line.  -> ({line index: [(a0, a1, score)] along the line's axis
     relative to its centre, sorted}, mask over ``q``)."""
     taken = np.zeros((q.shape[0],), bool)
     spans: dict = {}
