@@ -406,6 +406,9 @@ def test_page_warnings_reach_the_status_record_and_the_metrics(ctx):
     with TestClient(app) as c:
         _post(c, b"%PDF-1.4 warn", "w1")
         assert _wait(c, "w1") == "completed"
+        t_end = time.time() + 10.0          # the record turns "completed" with the stored result, the job's own update follows
+        while "warnings" not in status.get("w1") and time.time() < t_end:
+            time.sleep(0.02)
         assert status.get("w1")["warnings"] == warn
         text = c.get("/metrics").text
         assert 'ocr_page_warnings_total{reason="low_confidence"}' in text and 'ocr_page_warnings_total{reason="damaged"}' in text
