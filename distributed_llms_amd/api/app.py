@@ -5,7 +5,7 @@ Same public contract as the reference service
 
     POST /extract                multipart ``file`` + ``document_id``  -> {"status": "ok"} | raw status of a duplicate
     GET  /check-status/{id}      -> {"status": processing|completed|error} | 404 {'status': 'unknown', 'error': ...}
-    GET  /result/{id}            -> {"document_id", "text", "status": "completed"} | in-progress status | 404 | 500
+    GET  /result/{id}            -> {"document_id", "text", "status": "completed" [, "warnings"]} | in-progress status | 404 | 500
     GET  /health                 -> healthy 200 | degraded 200 | unhealthy 503, version "1.0.0"
     GET  /metrics                -> Prometheus text (new)
 
@@ -321,8 +321,12 @@ def create_app(settings: Optional[Settings] = None, status: Optional[StatusStore
             doc = await jobs._io(jobs.results.find, document_id)
             if doc:
                 _count("result", 200)
-                return JSONResponse({"document_id": document_id, "text": doc.get("combined_text", ""),
-                                     "status": "completed"})
+                body = {"document_id": document_id, "text": doc.get("combined_text", ""), "status": "completed"}
+                if status_data and status_data.get("warnings"):
+                    # beyond the reference's three keys, and only when there is something to say: pages whose image was
+                    # damaged or whose text was read with low confidence (a script the recogniser does not know)
+                    body["warnings"] = status_data["warnings"]
+                return JSONResponse(body)
             _count("result", 404)
             return JSONResponse({"error": f"No record found for document ID: {document_id}"}, status_code=404)
         except Exception as e:  # noqa: BLE001

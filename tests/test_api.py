@@ -410,6 +410,7 @@ def test_page_warnings_reach_the_status_record_and_the_metrics(ctx):
         while "warnings" not in status.get("w1") and time.time() < t_end:
             time.sleep(0.02)
         assert status.get("w1")["warnings"] == warn
+        assert c.get("/result/w1").json() == {"document_id": "w1", "text": "some text", "status": "completed", "warnings": warn}
         text = c.get("/metrics").text
         assert 'ocr_page_warnings_total{reason="low_confidence"}' in text and 'ocr_page_warnings_total{reason="damaged"}' in text
     assert metrics.PAGE_WARNINGS.labels("damaged")._value.get() == before["damaged"] + 1
